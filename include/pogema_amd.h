@@ -1,0 +1,157 @@
+/*
+ * pogema_amd.h -- C-ABI of the MI355X-native vectorized POGEMA step engine.
+ *
+ * This is the drop-in boundary for the reference's hot path.  The reference
+ * is pure Python and exposes no FFI; the entry points below are what a ctypes binding for
+ * `pogema/grid.py` + `pogema/envs.py` (reset()/step()) binds instead of the per-agent Python loops.
+ * The mounted reference is a stub (/root/reference/README.md:3,5 -- "code is hosted elsewhere"), so
+ * upstream files are cited by name only, never by line; see DESIGN.md "Parity status".
+ *
+ * Conventions
+ *   - every function returns an int status: 0 = ok, negative = error (PGX_E_*); nothing throws
+ *     across the ABI; pgx_last_error() returns a thread-local human-readable message.
+ *   - all I/O buffers are owned by the caller.  Pointers documented "device" must be device
+ *     pointers on the engine's device (e.g. torch tensor .data_ptr()); "host" are host pointers.
+ *   - the engine owns its internal SoA state (obstacle bitmaps, agent/target xy, active masks,
+ *     step counters) in HBM on its device.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  All device work is
+ *     enqueued asynchronously on it; no entry point synchronises unless documented.
+ *   - one pgx_env per device shard; a handle is not thread-safe, independent handles may be driven
+ *     from different host threads.
+ *   - coordinates at the ABI are UNPADDED map coordinates, (x = row, y = column), int32 pairs.
+ */
+#ifndef POGEMA_AMD_H
+#define POGEMA_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGX_ABI_VERSION 1
+
+/* error codes */
+#define PGX_OK 0
+#define PGX_E_INVALID (-1)   /* bad argument / config out of the supported range      */
+#define PGX_E_HIP (-2)       /* a HIP runtime call failed (message has the HIP error)  */
+#define PGX_E_NOMEM (-3)
+#define PGX_E_STATE (-4)     /* call order violated (e.g. step before reset)           */
+#define PGX_E_PLACEMENT (-5) /* generator could not place the requested agents         */
+
+/* collision systems -- replaces `Pogema.move_agents` branches (upstream pogema/envs.py) */
+#define PGX_COLLISION_PRIORITY 0
+#define PGX_COLLISION_BLOCK_BOTH 1
+#define PGX_COLLISION_SOFT 2
+
+/* on_target modes -- replaces Pogema / PogemaLifeLong / PogemaCoopFinish */
+#define PGX_ON_TARGET_FINISH 0
+#define PGX_ON_TARGET_RESTART 1
+#define PGX_ON_TARGET_NOTHING 2
+
+/* dtype of the `actions` buffer handed to pgx_step */
+#define PGX_ACTION_I8 0
+#define PGX_ACTION_I32 1
+#define PGX_ACTION_I64 2
+
+/* hard limits of this build */
+#define PGX_MAX_OBS_RADIUS 15   /* window side 2r+1 <= 31 (one 32-bit row mask per window row) */
+#define PGX_MAX_AGENTS 1024
+#define PGX_MAX_SIDE 1024
+
+/* Mirrors the step-relevant fields of the reference's `GridConfig` (upstream
+ * pogema/grid_config.py) plus the batch geometry. */
+typedef struct pgx_config {
+    int32_t batch;             /* envs held by this handle (this device's shard)               */
+    int32_t height, width;     /* unpadded map size (rectangular maps allowed)                 */
+    int32_t num_agents;
+    int32_t obs_radius;
+    int32_t collision_system;  /* PGX_COLLISION_*                                              */
+    int32_t on_target;         /* PGX_ON_TARGET_*                                              */
+    int32_t max_episode_steps; /* MultiTimeLimit; <= 0 disables truncation        */
+    int32_t auto_reset;        /* 1: an env whose agents are all terminated or truncated is   */
+                               /*    reset to its stored initial state inside the same step    */
+    int32_t reserved0;
+    uint64_t seed;             /* lifelong (restart) target stream seed                        */
+    int64_t env_index_base;    /* global index of env 0 of this shard (keeps lifelong streams  */
+                               /* independent of how the batch is sharded over devices)        */
+} pgx_config;
+
+typedef struct pgx_env pgx_env; /* opaque */
+
+/* ---- lifecycle -------------------------------------------------------------------------------- */
+int pgx_abi_version(void);
+const char* pgx_last_error(void);
+
+/* Allocates the device-resident SoA state for cfg->batch environments on `device`.
+ * Replaces: constructing `batch` reference env objects (upstream pogema/envs.py `_make_pogema`). */
+int pgx_create(const pgx_config* cfg, int device, pgx_env** out);
+int pgx_destroy(pgx_env* env);
+
+/* Sizes of the caller-owned output buffers, in elements. */
+int64_t pgx_obs_elems(const pgx_env* env);   /* batch * agents * 3 * (2r+1)^2   (float32) */
+int64_t pgx_agent_elems(const pgx_env* env); /* batch * agents                            */
+
+/* ---- reset -------------------------------------------------------------------------------------- */
+/* Installs initial states.  Replaces `Grid.__init__` + `add_artificial_border` (upstream
+ * pogema/grid.py) for explicitly given maps/positions.
+ *   obstacles  device u8  [batch, height, width]   0 = FREE, 1 = OBSTACLE
+ *   agent_xy   device i32 [batch, agents, 2]       unpadded (row, col)
+ *   target_xy  device i32 [batch, agents, 2]
+ * The state is also stored as the auto-reset state.  For on_target = RESTART this call additionally
+ * labels connected components on the host (it synchronises `stream`); otherwise it is async. */
+int pgx_reset_from_state(pgx_env* env, const uint8_t* obstacles, const int32_t* agent_xy,
+                         const int32_t* target_xy, void* stream);
+
+/* ---- the hot path ------------------------------------------------------------------------------- */
+/* One environment step for every env of the shard.  Replaces, per env, `Pogema.step` /
+ * `PogemaLifeLong.step` / `PogemaCoopFinish.step` including `move_agents`, `Grid.move`, the
+ * `_obs()` gather (`get_obstacles_for_agent`, `get_positions`, `get_square_target`) and
+ * `MultiTimeLimit.step` (upstream pogema/envs.py, pogema/grid.py,
+ * pogema/wrappers/multi_time_limit.py).
+ *   actions      device [batch, agents] of action_dtype, values 0..4 (noop, up, down, left, right)
+ *   obs          device f32 [batch, agents, 3, 2r+1, 2r+1]  (obstacles, agents, target)   may be NULL
+ *   rewards      device f32 [batch, agents]
+ *   terminated   device u8  [batch, agents]
+ *   truncated    device u8  [batch, agents]
+ *   is_active    device u8  [batch, agents]   infos[i]['is_active'] after the step      may be NULL */
+int pgx_step(pgx_env* env, const void* actions, int action_dtype, float* obs, float* rewards,
+             uint8_t* terminated, uint8_t* truncated, uint8_t* is_active, void* stream);
+
+/* Observation of the current state without stepping.  Replaces `PogemaBase._obs()` as called by
+ * `reset()`. */
+int pgx_observe(pgx_env* env, float* obs, void* stream);
+
+/* ---- state export ------------------------------------------------------------------------------- */
+/* Replaces `Grid.get_agents_xy` / `get_targets_xy` / `is_active` / the occupancy array (`positions`).
+ * Any pointer may be NULL.  All device pointers.
+ *   agent_xy, target_xy  i32 [batch, agents, 2] unpadded
+ *   is_active            u8  [batch, agents]
+ *   elapsed              i32 [batch]                        steps since the env's last reset
+ *   occupancy            u8  [batch, height+2r, width+2r]   padded occupancy array */
+int pgx_get_state(pgx_env* env, int32_t* agent_xy, int32_t* target_xy, uint8_t* is_active,
+                  int32_t* elapsed, uint8_t* occupancy, void* stream);
+
+/* ---- host-side synthetic map generator ------------------------------------------------------------ */
+/* Fills host buffers with `batch` random solvable instances: Bernoulli(density) obstacles, starts and
+ * targets on distinct free cells with each start/target pair in one 4-connected component.
+ * Plays the role of upstream pogema/generator.py at reset; the random stream is this
+ * build's own (numpy's PCG64 sequence is not reproduced -- DESIGN.md).  Env i uses seed0 + i.
+ *   obstacles host u8 [batch, height, width]; agent_xy / target_xy host i32 [batch, agents, 2]
+ * nthreads <= 0 picks the number of online cores.  Returns PGX_E_PLACEMENT if an env cannot be
+ * filled after `max_retries` re-draws. */
+int pgx_generate(int32_t batch, int32_t height, int32_t width, int32_t num_agents, float density,
+                 uint64_t seed0, int32_t max_retries, int32_t nthreads, uint8_t* obstacles,
+                 int32_t* agent_xy, int32_t* target_xy);
+
+/* Same placement on GIVEN obstacle maps (custom `GridConfig.map`): only starts/targets are drawn.
+ *   obstacles host u8 [batch, height, width], or [height, width] when shared_map != 0. */
+int pgx_place_agents(int32_t batch, int32_t height, int32_t width, int32_t num_agents, uint64_t seed0,
+                     int32_t max_retries, int32_t nthreads, const uint8_t* obstacles, int32_t shared_map,
+                     int32_t* agent_xy, int32_t* target_xy);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POGEMA_AMD_H */

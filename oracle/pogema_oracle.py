@@ -1,0 +1,347 @@
+"""CPU ORACLE (test infrastructure only) -- literal pure-Python restatement of POGEMA's step path.
+
+    *** PARITY UNPINNED ***
+    /root/reference holds only a 5-line README (README.md:3,5 say the code lives in another
+    repository), `pogema`/`gymnasium` are not importable here, and no reference test or golden
+    vector exists in this container.  Everything below follows SURVEY.md section 8(a) rows A0..A13
+    (the written SPEC) plus the builder's recollection of upstream `pogema/grid.py`,
+    `pogema/envs.py` and `pogema/wrappers/multi_time_limit.py` (1.3-era).  No reference line numbers
+    are cited because none could be opened.  Open parity questions are listed in DESIGN.md.
+
+This module is imported ONLY by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product (pogema_amd/) never imports it.
+
+Data structures deliberately mirror the reference's (dicts keyed by (x, y) tuples, python lists,
+recursion) so that order-dependent behaviour (agent-index order, reverse-index revert order,
+list insertion order) is reproduced by construction rather than re-derived.
+
+Coordinates: `x` is the ROW index, `y` the COLUMN index (MOVES first index is row).
+All coordinates held by `Grid` are PADDED coordinates (shifted by +obs_radius), as upstream does
+after `add_artificial_border`.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+FREE = 0
+OBSTACLE = 1
+# noop, up, down, left, right ; first index is the row.
+MOVES = ((0, 0), (-1, 0), (1, 0), (0, -1), (0, 1))
+
+COLLISION_SYSTEMS = ("priority", "block_both", "soft")
+ON_TARGET = ("finish", "restart", "nothing")
+
+_MASK32 = 0xFFFFFFFF
+_MASK64 = 0xFFFFFFFFFFFFFFFF
+
+
+# ----------------------------------------------------------------------------------------------
+# Lifelong target RNG.  The reference draws from per-agent numpy PCG64 generators
+# (SURVEY A7); that stream cannot be reproduced without the source, so the build defines its own
+# counter-based generator.  It is part of the build's SPEC (DESIGN.md "lifelong RNG") and is
+# shared verbatim by oracle/pogema_oracle.c and the HIP kernel.
+# ----------------------------------------------------------------------------------------------
+def splitmix64(z: int) -> int:
+    z = (z + 0x9E3779B97F4A7C15) & _MASK64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _MASK64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _MASK64
+    return z ^ (z >> 31)
+
+
+def lifelong_draw(seed: int, env_index: int, agent: int, counter: int, n: int) -> int:
+    """Uniform index in [0, n) for the `counter`-th target of `agent` in global env `env_index`."""
+    h = splitmix64(seed & _MASK64)
+    h = splitmix64(h ^ (env_index & _MASK64))
+    h = splitmix64(h ^ ((agent & _MASK32) << 32 | (counter & _MASK32)))
+    return ((h >> 32) * n) >> 32
+
+
+def label_components(obstacles: np.ndarray):
+    """4-connected components of FREE cells, ids in row-major order of first cell (0-based);
+    obstacle cells get -1.  Returns (labels, list_of_point_lists) with points row-major."""
+    h, w = obstacles.shape
+    labels = -np.ones((h, w), dtype=np.int64)
+    comps = []
+    for sx in range(h):
+        for sy in range(w):
+            if obstacles[sx, sy] != FREE or labels[sx, sy] >= 0:
+                continue
+            cid = len(comps)
+            labels[sx, sy] = cid
+            stack = [(sx, sy)]
+            while stack:
+                x, y = stack.pop()
+                for dx, dy in MOVES[1:]:
+                    nx, ny = x + dx, y + dy
+                    if 0 <= nx < h and 0 <= ny < w and obstacles[nx, ny] == FREE and labels[nx, ny] < 0:
+                        labels[nx, ny] = cid
+                        stack.append((nx, ny))
+            comps.append(None)
+    pts = [[] for _ in comps]
+    for x in range(h):
+        for y in range(w):
+            if labels[x, y] >= 0:
+                pts[labels[x, y]].append((x, y))
+    return labels, pts
+
+
+class Grid:
+    """SURVEY A1/A2/A9/A10/A11 (upstream `pogema/grid.py: Grid`)."""
+
+    def __init__(self, obstacles, agents_xy, targets_xy, obs_radius, empty_outside=True):
+        obstacles = np.asarray(obstacles)
+        assert obstacles.ndim == 2
+        self.r = int(obs_radius)
+        self.map_h, self.map_w = obstacles.shape
+        self.num_agents = len(agents_xy)
+        assert len(targets_xy) == self.num_agents
+        assert empty_outside, "empty_outside=False draws from the reference RNG; not restated"
+        self._raw_obstacles = obstacles.astype(np.int32)
+        # --- add_artificial_border (A1): pad by r, wall ring at offset r-1, outside FREE -------
+        r = self.r
+        filled = np.zeros((self.map_h + 2 * r, self.map_w + 2 * r), dtype=np.int32)
+        height, width = filled.shape
+        filled[r - 1, r - 1:width - r + 1] = OBSTACLE
+        filled[r - 1:height - r + 1, r - 1] = OBSTACLE
+        filled[height - r, r - 1:width - r + 1] = OBSTACLE
+        filled[r - 1:height - r + 1, width - r] = OBSTACLE
+        filled[r:height - r, r:width - r] = self._raw_obstacles
+        self.obstacles = filled
+        self.positions_xy = [(int(x) + r, int(y) + r) for x, y in agents_xy]
+        self.finishes_xy = [(int(x) + r, int(y) + r) for x, y in targets_xy]
+        for x, y in self.positions_xy + self.finishes_xy:
+            if self.obstacles[x, y] != FREE:
+                raise KeyError("agent or target placed on an obstacle")
+        if len(set(self.positions_xy)) != self.num_agents:
+            raise KeyError("two agents share a start cell")
+        # occupancy array (A1): 1 where an active, non-hidden agent stands
+        self.positions = np.zeros(filled.shape, dtype=np.int32)
+        for x, y in self.positions_xy:
+            self.positions[x, y] = OBSTACLE
+        self.is_active = {i: True for i in range(self.num_agents)}
+
+    # -- A2 ------------------------------------------------------------------------------------
+    def move(self, agent_id, action):
+        x, y = self.positions_xy[agent_id]
+        dx, dy = MOVES[action]
+        if self.obstacles[x + dx, y + dy] == FREE:
+            if self.positions[x + dx, y + dy] == FREE:
+                self.positions[x, y] = FREE
+                x += dx
+                y += dy
+                self.positions[x, y] = OBSTACLE
+        self.positions_xy[agent_id] = (x, y)
+
+    def has_obstacle(self, x, y):
+        return self.obstacles[x, y] == OBSTACLE
+
+    def on_goal(self, agent_id):
+        return self.positions_xy[agent_id] == self.finishes_xy[agent_id]
+
+    def hide_agent(self, agent_id):
+        if not self.is_active[agent_id]:
+            return False
+        self.is_active[agent_id] = False
+        self.positions[self.positions_xy[agent_id]] = FREE
+        return True
+
+    # -- A9 / A10 / A11 --------------------------------------------------------------------------
+    def get_obstacles_for_agent(self, agent_id):
+        x, y = self.positions_xy[agent_id]
+        r = self.r
+        return self.obstacles[x - r:x + r + 1, y - r:y + r + 1].astype(np.float32)
+
+    def get_positions(self, agent_id):
+        x, y = self.positions_xy[agent_id]
+        r = self.r
+        return self.positions[x - r:x + r + 1, y - r:y + r + 1].astype(np.float32)
+
+    def get_square_target(self, agent_id):
+        r = self.r
+        full = 2 * r + 1
+        result = np.zeros((full, full), dtype=np.float32)
+        x, y = self.positions_xy[agent_id]
+        fx, fy = self.finishes_xy[agent_id]
+        dx, dy = x - fx, y - fy
+        dx = min(dx, r) if dx >= 0 else max(dx, -r)
+        dy = min(dy, r) if dy >= 0 else max(dy, -r)
+        result[r - dx, r - dy] = 1.0
+        return result
+
+    def unpadded_xy(self, padded):
+        return [(x - self.r, y - self.r) for x, y in padded]
+
+
+class PogemaOracle:
+    """SURVEY A3..A8, A12, A13 (upstream `pogema/envs.py`: Pogema / PogemaLifeLong /
+    PogemaCoopFinish, wrapped by `MultiTimeLimit` and optionally the auto-reset wrapper).
+
+    One instance == one environment; batching is a python loop in the tests.
+    """
+
+    def __init__(self, obstacles, agents_xy, targets_xy, obs_radius=5, collision_system="priority",
+                 on_target="finish", max_episode_steps=64, auto_reset=False, seed=0, env_index=0):
+        assert collision_system in COLLISION_SYSTEMS and on_target in ON_TARGET
+        self._init_args = (np.array(obstacles, copy=True), [tuple(map(int, p)) for p in agents_xy],
+                           [tuple(map(int, p)) for p in targets_xy])
+        self.obs_radius = int(obs_radius)
+        self.collision_system = collision_system
+        self.on_target = on_target
+        self.max_episode_steps = int(max_episode_steps)
+        self.auto_reset = bool(auto_reset)
+        self.seed = int(seed)
+        self.env_index = int(env_index)
+        self.num_agents = len(agents_xy)
+        self.reset()
+
+    # ------------------------------------------------------------------------------------------
+    def reset(self):
+        obstacles, agents_xy, targets_xy = self._init_args
+        self.grid = Grid(obstacles, agents_xy, targets_xy, self.obs_radius)
+        self._elapsed_steps = 0
+        if self.on_target == "restart":
+            labels, pts = label_components(np.asarray(obstacles))
+            self._labels, self._comp_points = labels, pts
+            # counters survive auto-reset on purpose: the reference re-seeds its generators at
+            # reset; the build keeps a monotone per-agent counter instead.
+            if not hasattr(self, "_target_counter"):
+                self._target_counter = [0] * self.num_agents
+        return self._obs()
+
+    # -- A12 -----------------------------------------------------------------------------------
+    def _obs(self):
+        g = self.grid
+        return [np.concatenate([g.get_obstacles_for_agent(i)[None], g.get_positions(i)[None],
+                                g.get_square_target(i)[None]]) for i in range(self.num_agents)]
+
+    # -- A5 helper -------------------------------------------------------------------------------
+    def _revert_action(self, agent_idx, used_cells, cell, actions):
+        actions[agent_idx] = 0
+        used_cells[cell].remove(agent_idx)
+        new_cell = self.grid.positions_xy[agent_idx]
+        if new_cell in used_cells and len(used_cells[new_cell]) > 0:
+            used_cells[new_cell].append(agent_idx)
+            return self._revert_action(used_cells[new_cell][0], used_cells, new_cell, actions)
+        used_cells.setdefault(new_cell, []).append(agent_idx)
+        return actions, used_cells
+
+    # -- A3 / A4 / A5 ------------------------------------------------------------------------------
+    def move_agents(self, actions):
+        g = self.grid
+        n = self.num_agents
+        if self.collision_system == "priority":
+            for i in range(n):
+                if g.is_active[i]:
+                    g.move(i, actions[i])
+        elif self.collision_system == "block_both":
+            used_cells = {}
+            agents_xy = list(g.positions_xy)
+            for i, (x, y) in enumerate(agents_xy):
+                if g.is_active[i]:
+                    dx, dy = MOVES[actions[i]]
+                    used_cells[x + dx, y + dy] = "blocked" if (x + dx, y + dy) in used_cells else "visited"
+                    used_cells[x, y] = "blocked"
+            for i in range(n):
+                if g.is_active[i]:
+                    x, y = agents_xy[i]
+                    dx, dy = MOVES[actions[i]]
+                    if used_cells.get((x + dx, y + dy), None) != "blocked":
+                        g.move(i, actions[i])
+        else:  # soft
+            actions = list(actions)
+            used_cells = {}
+            used_edges = {}
+            agents_xy = list(g.positions_xy)
+            for i, (x, y) in enumerate(agents_xy):
+                if g.is_active[i]:
+                    dx, dy = MOVES[actions[i]]
+                    used_cells.setdefault((x + dx, y + dy), []).append(i)
+                    used_edges[x, y, x + dx, y + dy] = [i]
+                    if dx != 0 or dy != 0:
+                        used_edges.setdefault((x + dx, y + dy, x, y), []).append(i)
+            for i, (x, y) in enumerate(agents_xy):
+                if g.is_active[i]:
+                    dx, dy = MOVES[actions[i]]
+                    if len(used_edges[x, y, x + dx, y + dy]) > 1:
+                        used_cells[x + dx, y + dy].remove(i)
+                        used_cells.setdefault((x, y), []).append(i)
+                        actions[i] = 0
+            for i in reversed(range(n)):
+                x, y = agents_xy[i]
+                if g.is_active[i]:
+                    dx, dy = MOVES[actions[i]]
+                    if len(used_cells[x + dx, y + dy]) > 1 or g.has_obstacle(x + dx, y + dy):
+                        self._revert_action(i, used_cells, (x + dx, y + dy), actions)
+            # move_without_checks: the surviving moves are mutually compatible, so the occupancy
+            # array afterwards is exactly the set of active agents' cells (DESIGN.md open
+            # question 2: upstream's per-agent clear/set order is not recalled with confidence).
+            for i in range(n):
+                if g.is_active[i]:
+                    x, y = g.positions_xy[i]
+                    g.positions[x, y] = FREE
+            for i in range(n):
+                if g.is_active[i]:
+                    x, y = g.positions_xy[i]
+                    dx, dy = MOVES[actions[i]]
+                    g.positions_xy[i] = (x + dx, y + dy)
+                    g.positions[x + dx, y + dy] = OBSTACLE
+
+    # -- A6 / A7 / A8 + A13 + auto-reset ---------------------------------------------------------
+    def step(self, actions):
+        actions = [int(a) for a in actions]
+        assert len(actions) == self.num_agents
+        g = self.grid
+        n = self.num_agents
+        self.move_agents(actions)
+        if self.on_target == "finish":
+            rewards, terminated = [], []
+            for i in range(n):
+                on_goal = g.on_goal(i)
+                rewards.append(1.0 if (on_goal and g.is_active[i]) else 0.0)
+                terminated.append(bool(on_goal))
+            for i in range(n):
+                if g.on_goal(i):
+                    g.hide_agent(i)
+                    g.is_active[i] = False
+        elif self.on_target == "restart":
+            rewards = []
+            for i in range(n):
+                on_goal = g.on_goal(i)
+                rewards.append(1.0 if (on_goal and g.is_active[i]) else 0.0)
+                if on_goal:
+                    g.finishes_xy[i] = self._generate_new_target(i)
+            terminated = [False] * n
+        else:  # nothing (cooperative finish)
+            solved = all(g.on_goal(i) and g.is_active[i] for i in range(n))
+            rewards = [1.0 if solved else 0.0] * n
+            terminated = [bool(solved)] * n
+        infos = [{"is_active": bool(g.is_active[i])} for i in range(n)]
+        truncated = [False] * n
+        # A13 MultiTimeLimit
+        self._elapsed_steps += 1
+        if self._elapsed_steps >= self.max_episode_steps:
+            truncated = [True] * n
+        obs = self._obs()
+        if self.auto_reset and (all(terminated) or all(truncated)):
+            obs = self.reset()
+        return obs, rewards, terminated, truncated, infos
+
+    def _generate_new_target(self, agent_idx):
+        r = self.obs_radius
+        x, y = self.grid.positions_xy[agent_idx]
+        comp = self._comp_points[self._labels[x - r, y - r]]
+        k = lifelong_draw(self.seed, self.env_index, agent_idx, self._target_counter[agent_idx], len(comp))
+        self._target_counter[agent_idx] += 1
+        tx, ty = comp[k]
+        return (tx + r, ty + r)
+
+    # -- state export (unpadded coordinates), used by parity tests ---------------------------------
+    def get_state(self):
+        g = self.grid
+        return {
+            "agents_xy": np.array(g.unpadded_xy(g.positions_xy), dtype=np.int32).reshape(-1, 2),
+            "targets_xy": np.array(g.unpadded_xy(g.finishes_xy), dtype=np.int32).reshape(-1, 2),
+            "is_active": np.array([g.is_active[i] for i in range(self.num_agents)], dtype=np.uint8),
+            "elapsed": self._elapsed_steps,
+            "occupancy": g.positions.astype(np.uint8).copy(),
+        }

@@ -1,0 +1,20 @@
+"""pogema_amd -- MI355X-native vectorized POGEMA step engine (drop-in for the reference's
+grid.py / envs.py reset()/step() hot path).  See DESIGN.md."""
+from .grid_config import (GridConfig, Easy8x8, Normal8x8, Hard8x8, Easy16x16, Hard16x16, Easy32x32,
+                          Hard32x32, Easy64x64, Hard64x64)
+
+__version__ = "0.1.0"
+
+__all__ = ["GridConfig", "VecPogema", "Pogema", "pogema_v0", "Easy8x8", "Normal8x8", "Hard8x8", "Easy16x16",
+           "Hard16x16", "Easy32x32", "Hard32x32", "Easy64x64", "Hard64x64"]
+
+
+def __getattr__(name):
+    # engine classes import torch + the HIP library lazily so that `GridConfig` stays importable anywhere
+    if name == "VecPogema":
+        from .vec_env import VecPogema
+        return VecPogema
+    if name in ("Pogema", "pogema_v0", "PogemaParallel"):
+        from . import envs
+        return getattr(envs, name)
+    raise AttributeError(name)

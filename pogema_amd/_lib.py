@@ -1,0 +1,85 @@
+"""ctypes binding of libpogema_amd.so (the C-ABI declared in include/pogema_amd.h).
+
+There is deliberately NO fallback: if the HIP library is missing or cannot be loaded the import of
+the engine raises, and every compute call raises `PgxError` when the device is unusable.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpogema_amd.so")
+
+PGX_ABI_VERSION = 1
+
+COLLISION_SYSTEMS = {"priority": 0, "block_both": 1, "soft": 2}
+ON_TARGET = {"finish": 0, "restart": 1, "nothing": 2}
+ACTION_DTYPES = {"int8": 0, "int32": 1, "int64": 2}
+
+# every symbol include/pogema_amd.h declares; tests/test_abi.py checks the library exports them all
+EXPORTED_SYMBOLS = (
+    "pgx_abi_version", "pgx_last_error", "pgx_create", "pgx_destroy", "pgx_obs_elems", "pgx_agent_elems",
+    "pgx_reset_from_state", "pgx_step", "pgx_observe", "pgx_get_state", "pgx_generate", "pgx_place_agents",
+)
+
+
+class PgxError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"pogema_amd engine error {code}: {message}")
+        self.code = code
+
+
+class PgxConfig(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("num_agents", C.c_int32),
+        ("obs_radius", C.c_int32), ("collision_system", C.c_int32), ("on_target", C.c_int32),
+        ("max_episode_steps", C.c_int32), ("auto_reset", C.c_int32), ("reserved0", C.c_int32),
+        ("seed", C.c_uint64), ("env_index_base", C.c_int64),
+    ]
+
+
+_lib = None
+
+
+def build_hint() -> str:
+    return ("build it with `python -c 'import __graft_entry__ as g; g.build()'` from the repo root "
+            "(or `make -C pogema_amd/csrc`)")
+
+
+def load() -> C.CDLL:
+    """Load the engine library once; raises ImportError loudly when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found: the HIP engine is not built; {build_hint()}")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, u64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
+    lib.pgx_abi_version.restype = C.c_int
+    lib.pgx_last_error.restype = C.c_char_p
+    lib.pgx_create.argtypes = [C.POINTER(PgxConfig), C.c_int, C.POINTER(vp)]
+    lib.pgx_destroy.argtypes = [vp]
+    lib.pgx_obs_elems.argtypes = [vp]
+    lib.pgx_obs_elems.restype = i64
+    lib.pgx_agent_elems.argtypes = [vp]
+    lib.pgx_agent_elems.restype = i64
+    lib.pgx_reset_from_state.argtypes = [vp, vp, vp, vp, vp]
+    lib.pgx_step.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
+    lib.pgx_observe.argtypes = [vp, vp, vp]
+    lib.pgx_get_state.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.pgx_generate.argtypes = [i32, i32, i32, i32, f32, u64, i32, i32, vp, vp, vp]
+    lib.pgx_place_agents.argtypes = [i32, i32, i32, i32, u64, i32, i32, vp, i32, vp, vp]
+    for name in ("pgx_create", "pgx_destroy", "pgx_reset_from_state", "pgx_step", "pgx_observe",
+                 "pgx_get_state", "pgx_generate", "pgx_place_agents"):
+        getattr(lib, name).restype = C.c_int
+    if lib.pgx_abi_version() != PGX_ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI version {lib.pgx_abi_version()} != expected {PGX_ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(status: int) -> None:
+    if status != 0:
+        msg = load().pgx_last_error()
+        raise PgxError(status, msg.decode("utf-8", "replace") if msg else "unknown error")

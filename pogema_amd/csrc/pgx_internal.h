@@ -1,0 +1,62 @@
+// pgx_internal.h -- shared between pgx_kernels.hip (device code + launchers) and pgx_api.cpp (C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace pgx {
+
+enum { MODE_STEP = 0, MODE_OBSERVE = 1 };
+enum { COLLISION_PRIORITY = 0, COLLISION_BLOCK_BOTH = 1, COLLISION_SOFT = 2 };
+enum { ON_TARGET_FINISH = 0, ON_TARGET_RESTART = 1, ON_TARGET_NOTHING = 2 };
+
+// Kernel argument block of the step kernel (passed by value: lands in SGPRs / kernarg segment).
+struct StepParams {
+    // geometry
+    int32_t batch, num_agents, r;
+    int32_t wpr;       // 32-bit words per padded bitmap row
+    int32_t bm_words;  // words per env bitmap = (H + 2r) * wpr
+    int32_t map_w;     // unpadded width
+    int32_t map_cells; // unpadded H * W
+    uint32_t w_magic;  // ceil(2^32 / (2r+1)): exact division of flat window offsets by the window side
+    // behaviour
+    int32_t mode, collision, on_target, max_steps, auto_reset, action_dtype;
+    uint64_t seed;
+    int64_t env_index_base;
+    // SoA state in HBM
+    const uint32_t* obst;  // [B][bm_words]   padded obstacle bitmap, 1 bit per cell
+    uint32_t* pos;         // [B][A]          (x << 16) | y, padded coordinates
+    uint32_t* tgt;         // [B][A]
+    uint8_t* active;       // [B][A]
+    int32_t* elapsed;      // [B]
+    const uint32_t* pos0;  // [B][A]          auto-reset state
+    const uint32_t* tgt0;  // [B][A]
+    // lifelong (on_target = restart) tables, unpadded cell index = x * map_w + y
+    const uint32_t* comp_begin;  // [B][H*W]  offset of the cell's component inside comp_cells
+    const uint32_t* comp_len;    // [B][H*W]  size of the cell's component
+    const uint32_t* comp_cells;  // [B][H*W]  unpadded packed cells grouped by component, row-major inside
+    uint32_t* tcount;            // [B][A]    targets drawn so far
+    // I/O (caller-owned device buffers)
+    const void* actions;
+    float* obs;
+    float* rewards;
+    uint8_t* terminated;
+    uint8_t* truncated;
+    uint8_t* act_out;
+};
+
+hipError_t launch_step(const StepParams& p, int K, int G, size_t lds_bytes, hipStream_t stream);
+size_t step_lds_bytes(int K, int G, int A, int bmw, int W);
+
+hipError_t launch_pack_obstacles(const uint8_t* obstacles, uint32_t* bm, int batch, int H, int Wd, int r,
+                                 int wpr, int bmw, hipStream_t stream);
+hipError_t launch_pack_agents(const int32_t* agent_xy, const int32_t* target_xy, uint32_t* pos, uint32_t* tgt,
+                              uint32_t* pos0, uint32_t* tgt0, uint8_t* active, uint32_t* tcount, size_t n,
+                              int r, hipStream_t stream);
+hipError_t launch_zero_i32(int32_t* v, size_t n, hipStream_t stream);
+hipError_t launch_unpack_state(const uint32_t* pos, const uint32_t* tgt, const uint8_t* active, int32_t* agent_xy,
+                               int32_t* target_xy, uint8_t* act_out, size_t n, int r, hipStream_t stream);
+hipError_t launch_occupancy(const uint32_t* pos, const uint8_t* active, uint8_t* occ, size_t n, int A, int PH,
+                            int PW, hipStream_t stream);
+
+}  // namespace pgx

@@ -1,0 +1,126 @@
+"""Single-environment, list-per-agent view of the engine: the reference's native calling convention
+(upstream `pogema/envs.py` + `pogema/integrations/make_pogema.py`: `pogema_v0(grid_config)`;
+SURVEY.md section 8b "what the reference exposes").
+
+    env = pogema_v0(GridConfig(num_agents=2, size=8))
+    obs, infos = env.reset()
+    obs, rewards, terminated, truncated, infos = env.step([0, 3])
+
+`obs[i]` is a float32 numpy array (3, 2r+1, 2r+1); rewards floats; terminated/truncated bools; infos
+dicts with 'is_active'.  Everything is computed by the HIP engine with batch = 1 (this view exists
+for API compatibility and tests, not for throughput -- use `VecPogema` for that).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+from .grid_config import GridConfig
+from .vec_env import VecPogema
+
+try:  # gymnasium is optional (not installed in the build image)
+    import gymnasium  # type: ignore
+    _Box, _Discrete = gymnasium.spaces.Box, gymnasium.spaces.Discrete
+except Exception:  # pragma: no cover - exercised only where gymnasium is missing
+    class _Box:  # minimal duck-typed stand-ins
+        def __init__(self, low, high, shape, dtype=np.float32):
+            self.low, self.high, self.shape, self.dtype = low, high, tuple(shape), dtype
+
+        def contains(self, x):
+            x = np.asarray(x)
+            return x.shape == self.shape and (x >= self.low).all() and (x <= self.high).all()
+
+    class _Discrete:
+        def __init__(self, n):
+            self.n = n
+            self._rng = np.random.default_rng()
+
+        def sample(self):
+            return int(self._rng.integers(self.n))
+
+        def contains(self, x):
+            return 0 <= int(x) < self.n
+
+
+class Pogema:
+    def __init__(self, grid_config: Optional[GridConfig] = None, device="cuda:0"):
+        self.grid_config = grid_config if grid_config is not None else GridConfig(num_agents=2)
+        self._vec = VecPogema(self.grid_config, batch=1, device=device)
+        full = 2 * self.grid_config.obs_radius + 1
+        self.observation_space = _Box(0.0, 1.0, shape=(3, full, full), dtype=np.float32)
+        self.action_space = _Discrete(len(self.grid_config.MOVES))
+
+    def get_num_agents(self):
+        return self.grid_config.num_agents
+
+    def sample_actions(self):
+        return [self.action_space.sample() for _ in range(self.get_num_agents())]
+
+    @staticmethod
+    def _obs_list(obs):
+        host = obs[0].cpu().numpy()
+        return [host[i] for i in range(host.shape[0])]
+
+    def reset(self, seed: Optional[int] = None, return_info: bool = True, options=None):
+        obs, infos = self._vec.reset(seed=seed)
+        active = infos["is_active"][0].cpu().numpy()
+        out = self._obs_list(obs)
+        if return_info:
+            return out, [{"is_active": bool(a)} for a in active]
+        return out
+
+    def step(self, action):
+        assert len(action) == self.get_num_agents()
+        obs, rewards, terminated, truncated, infos = self._vec.step(np.asarray(action, dtype=np.int64)[None])
+        return (self._obs_list(obs), [float(v) for v in rewards[0].cpu().numpy()],
+                [bool(v) for v in terminated[0].cpu().numpy()], [bool(v) for v in truncated[0].cpu().numpy()],
+                [{"is_active": bool(v)} for v in infos["is_active"][0].cpu().numpy()])
+
+    # ---- state accessors in the style of `Grid.get_agents_xy` etc. (unpadded coordinates) ----------
+    def get_agents_xy(self):
+        return [tuple(int(c) for c in p) for p in self._vec.get_state()["agents_xy"][0].cpu().numpy()]
+
+    def get_targets_xy(self):
+        return [tuple(int(c) for c in p) for p in self._vec.get_state()["targets_xy"][0].cpu().numpy()]
+
+    def close(self):
+        self._vec.close()
+
+
+class PogemaParallel:
+    """PettingZoo-parallel-style dict view (agent names 'player_i'); thin adapter over `Pogema`."""
+
+    def __init__(self, grid_config: Optional[GridConfig] = None, device="cuda:0"):
+        self._env = Pogema(grid_config, device=device)
+        self.possible_agents = [f"player_{i}" for i in range(self._env.get_num_agents())]
+        self.agents = list(self.possible_agents)
+
+    def observation_space(self, agent):
+        return self._env.observation_space
+
+    def action_space(self, agent):
+        return self._env.action_space
+
+    def reset(self, seed=None, options=None):
+        obs, infos = self._env.reset(seed=seed)
+        self.agents = list(self.possible_agents)
+        return dict(zip(self.possible_agents, obs)), dict(zip(self.possible_agents, infos))
+
+    def step(self, actions: dict):
+        acts = [int(actions.get(name, 0)) for name in self.possible_agents]
+        obs, rew, term, trunc, infos = self._env.step(acts)
+        names = self.possible_agents
+        self.agents = [n for n, t, tr in zip(names, term, trunc) if not (t or tr)]
+        return (dict(zip(names, obs)), dict(zip(names, rew)), dict(zip(names, term)), dict(zip(names, trunc)),
+                dict(zip(names, infos)))
+
+
+def pogema_v0(grid_config: Optional[GridConfig] = None, device="cuda:0"):
+    """Factory with the reference's name: dispatches on `GridConfig.integration`."""
+    gc = grid_config if grid_config is not None else GridConfig(num_agents=2)
+    if gc.integration in (None, "gymnasium"):
+        return Pogema(gc, device=device)
+    if gc.integration == "PettingZoo":
+        return PogemaParallel(gc, device=device)
+    raise NotImplementedError(f"integration={gc.integration!r} is outside the hot-path scope of this build")

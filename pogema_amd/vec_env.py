@@ -1,0 +1,246 @@
+"""VecPogema -- batched, device-resident POGEMA environments driven through the C-ABI.
+
+Host-side mirror of the reference's `reset()` / `step()` surface (upstream `pogema/envs.py`:
+`Pogema`, `PogemaLifeLong`, `PogemaCoopFinish` + `MultiTimeLimit` + the auto-reset wrapper) for a
+whole batch of independent environments at once.  All state lives in HBM inside the engine; this
+class only owns the I/O tensors and forwards pointers.  torch is used for device memory and streams
+only -- every computation happens in libpogema_amd.so (there is no eager/CPU fallback).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .grid_config import GridConfig
+
+
+def _as_device_index(device) -> int:
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise ValueError(f"VecPogema runs on a HIP device only, got {device!r}")
+    return dev.index if dev.index is not None else torch.cuda.current_device()
+
+
+class VecPogema:
+    """`batch` independent POGEMA environments on one MI355X.
+
+    obs        float32 [batch, agents, 3, 2r+1, 2r+1]   (obstacles, agents, target)
+    rewards    float32 [batch, agents]
+    terminated / truncated   bool [batch, agents]
+    infos      {'is_active': bool [batch, agents]}
+    """
+
+    def __init__(self, grid_config: Optional[GridConfig] = None, batch: int = 1, device="cuda:0",
+                 env_index_base: int = 0, auto_reset: Optional[bool] = None, reuse_buffers: bool = False):
+        self.grid_config = grid_config if grid_config is not None else GridConfig(num_agents=2)
+        gc = self.grid_config
+        if gc.observation_type != "default":
+            raise NotImplementedError("only observation_type='default' is implemented by the engine")
+        if not gc.empty_outside:
+            raise NotImplementedError("empty_outside=False draws from the reference's RNG; not implemented")
+        if not torch.cuda.is_available():
+            raise RuntimeError("pogema_amd needs a HIP device (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        self._lib = _lib.load()
+        self.batch = int(batch)
+        self.num_agents = int(gc.num_agents)
+        self.obs_radius = int(gc.obs_radius)
+        self.window = 2 * self.obs_radius + 1
+        self.height, self.width = gc.map_shape
+        self.device_index = _as_device_index(device)
+        self.device = torch.device("cuda", self.device_index)
+        self.env_index_base = int(env_index_base)
+        if auto_reset is None:
+            auto_reset = bool(gc.auto_reset) if gc.auto_reset is not None else False
+        self.auto_reset = bool(auto_reset)
+        self.reuse_buffers = bool(reuse_buffers)
+        self._seed = gc.seed
+        cfg = _lib.PgxConfig(
+            batch=self.batch, height=self.height, width=self.width, num_agents=self.num_agents,
+            obs_radius=self.obs_radius, collision_system=_lib.COLLISION_SYSTEMS[gc.collision_system],
+            on_target=_lib.ON_TARGET[gc.on_target], max_episode_steps=int(gc.max_episode_steps),
+            auto_reset=int(self.auto_reset), reserved0=0, seed=int(gc.seed or 0),
+            env_index_base=self.env_index_base)
+        self._handle = C.c_void_p()
+        _lib.check(self._lib.pgx_create(C.byref(cfg), self.device_index, C.byref(self._handle)))
+        self._bufs = None
+        self._buf_i = 0
+        self._initial = None
+
+    # ------------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_handle", None) is not None and self._handle.value:
+            self._lib.pgx_destroy(self._handle)
+            self._handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    @property
+    def obs_shape(self):
+        return (self.batch, self.num_agents, 3, self.window, self.window)
+
+    def get_num_agents(self):
+        return self.num_agents
+
+    # ------------------------------------------------------------------------------------------
+    def generate(self, seed: Optional[int] = None):
+        """Host-side instance generation (engine's C++ generator); returns numpy
+        (obstacles u8 [B,H,W], agents_xy i32 [B,A,2], targets_xy i32 [B,A,2])."""
+        gc = self.grid_config
+        B, H, Wd, A = self.batch, self.height, self.width, self.num_agents
+        if seed is None:
+            seed = self._seed
+        if seed is None:
+            seed = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0] >> 1)
+        seed0 = (int(seed) + self.env_index_base) & 0xFFFFFFFFFFFFFFFF
+        agents = np.empty((B, A, 2), dtype=np.int32)
+        targets = np.empty((B, A, 2), dtype=np.int32)
+        if gc.map is not None:
+            one = np.ascontiguousarray(np.array(gc.map, dtype=np.uint8) != 0, dtype=np.uint8)
+            obstacles = np.ascontiguousarray(np.broadcast_to(one, (B, H, Wd)))
+            if gc.agents_xy is not None:
+                agents[:] = np.asarray(gc.agents_xy, dtype=np.int32)[None]
+                targets[:] = np.asarray(gc.targets_xy, dtype=np.int32)[None]
+            else:
+                _lib.check(self._lib.pgx_place_agents(B, H, Wd, A, seed0, 10, 0, one.ctypes.data, 1,
+                                                      agents.ctypes.data, targets.ctypes.data))
+        else:
+            obstacles = np.empty((B, H, Wd), dtype=np.uint8)
+            if gc.agents_xy is not None:
+                raise NotImplementedError("agents_xy/targets_xy need an explicit `map`")
+            _lib.check(self._lib.pgx_generate(B, H, Wd, A, float(gc.density), seed0, 10, 0,
+                                              obstacles.ctypes.data, agents.ctypes.data, targets.ctypes.data))
+        return obstacles, agents, targets
+
+    @staticmethod
+    def _validate_state(obstacles, agents, targets):
+        B, A = agents.shape[:2]
+        bi = np.arange(B)[:, None]
+        if (obstacles[bi, agents[..., 0], agents[..., 1]] != 0).any():
+            raise KeyError("an agent start lies on an obstacle")
+        if (obstacles[bi, targets[..., 0], targets[..., 1]] != 0).any():
+            raise KeyError("a target lies on an obstacle")
+        w = obstacles.shape[2]
+        flat = np.sort(agents[..., 0].astype(np.int64) * w + agents[..., 1], axis=1)
+        if A > 1 and (flat[:, 1:] == flat[:, :-1]).any():
+            raise KeyError("two agents share a start cell")
+
+    def reset_from_state(self, obstacles, agents_xy, targets_xy, validate: bool = True):
+        """Install explicit initial states (numpy or torch; broadcast over the batch when 2-D/3-D
+        inputs lack the batch axis) and return the first observation."""
+        B, H, Wd, A = self.batch, self.height, self.width, self.num_agents
+
+        def to_np(v, dtype):
+            if isinstance(v, torch.Tensor):
+                v = v.detach().cpu().numpy()
+            return np.asarray(v, dtype=dtype)
+
+        obstacles = to_np(obstacles, np.uint8)
+        agents_xy = to_np(agents_xy, np.int32)
+        targets_xy = to_np(targets_xy, np.int32)
+        if obstacles.ndim == 2:
+            obstacles = np.broadcast_to(obstacles, (B, H, Wd))
+        if agents_xy.ndim == 2:
+            agents_xy = np.broadcast_to(agents_xy, (B, A, 2))
+        if targets_xy.ndim == 2:
+            targets_xy = np.broadcast_to(targets_xy, (B, A, 2))
+        if obstacles.shape != (B, H, Wd) or agents_xy.shape != (B, A, 2) or targets_xy.shape != (B, A, 2):
+            raise ValueError(f"state shapes {obstacles.shape}, {agents_xy.shape}, {targets_xy.shape} do not match "
+                             f"batch={B}, map={H}x{Wd}, agents={A}")
+        for name, pts in (("agents_xy", agents_xy), ("targets_xy", targets_xy)):
+            if (pts[..., 0] < 0).any() or (pts[..., 0] >= H).any() or (pts[..., 1] < 0).any() or (pts[..., 1] >= Wd).any():
+                raise IndexError(f"{name} outside the {H}x{Wd} map")
+        obstacles = np.ascontiguousarray((obstacles != 0).astype(np.uint8))
+        agents_xy = np.ascontiguousarray(agents_xy)
+        targets_xy = np.ascontiguousarray(targets_xy)
+        if validate:
+            self._validate_state(obstacles, agents_xy, targets_xy)
+        d_obst = torch.from_numpy(obstacles).to(self.device)
+        d_agents = torch.from_numpy(agents_xy).to(self.device)
+        d_targets = torch.from_numpy(targets_xy).to(self.device)
+        _lib.check(self._lib.pgx_reset_from_state(self._handle, d_obst.data_ptr(), d_agents.data_ptr(),
+                                                  d_targets.data_ptr(), self._stream()))
+        self._initial = (d_obst, d_agents, d_targets)  # keep alive until the stream consumed them
+        return self.observe()
+
+    def reset(self, seed: Optional[int] = None, options=None):
+        """gymnasium-style reset: draws fresh instances (env i uses seed + env_index_base + i) and
+        returns (obs, infos)."""
+        obstacles, agents, targets = self.generate(seed)
+        obs = self.reset_from_state(obstacles, agents, targets, validate=False)
+        infos = {"is_active": torch.ones((self.batch, self.num_agents), dtype=torch.bool, device=self.device)}
+        return obs, infos
+
+    # ------------------------------------------------------------------------------------------
+    def _alloc_outputs(self):
+        B, A = self.batch, self.num_agents
+        dev = self.device
+        return (torch.empty(self.obs_shape, dtype=torch.float32, device=dev),
+                torch.empty((B, A), dtype=torch.float32, device=dev),
+                torch.empty((B, A), dtype=torch.bool, device=dev),
+                torch.empty((B, A), dtype=torch.bool, device=dev),
+                torch.empty((B, A), dtype=torch.bool, device=dev))
+
+    def _outputs(self):
+        if not self.reuse_buffers:
+            return self._alloc_outputs()
+        if self._bufs is None:
+            self._bufs = [self._alloc_outputs(), self._alloc_outputs()]
+        self._buf_i ^= 1
+        return self._bufs[self._buf_i]
+
+    def observe(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        obs = out if out is not None else torch.empty(self.obs_shape, dtype=torch.float32, device=self.device)
+        _lib.check(self._lib.pgx_observe(self._handle, obs.data_ptr(), self._stream()))
+        return obs
+
+    def _prepare_actions(self, actions) -> torch.Tensor:
+        if not isinstance(actions, torch.Tensor):
+            actions = torch.as_tensor(np.asarray(actions), device=self.device)
+        if actions.device != self.device:
+            actions = actions.to(self.device, non_blocking=True)
+        if actions.dtype not in (torch.int8, torch.int32, torch.int64):
+            actions = actions.to(torch.int64)
+        if actions.numel() != self.batch * self.num_agents:
+            raise ValueError(f"expected {self.batch}x{self.num_agents} actions, got shape {tuple(actions.shape)}")
+        return actions.contiguous()
+
+    _ACTION_CODE = {torch.int8: 0, torch.int32: 1, torch.int64: 2}
+
+    def step(self, actions, compute_obs: bool = True):
+        """One step of every environment.  `actions`: int tensor [batch, agents] with values 0..4
+        (noop, up, down, left, right).  Returns (obs, rewards, terminated, truncated, infos)."""
+        actions = self._prepare_actions(actions)
+        obs, rewards, terminated, truncated, is_active = self._outputs()
+        _lib.check(self._lib.pgx_step(
+            self._handle, actions.data_ptr(), self._ACTION_CODE[actions.dtype],
+            obs.data_ptr() if compute_obs else None, rewards.data_ptr(), terminated.data_ptr(),
+            truncated.data_ptr(), is_active.data_ptr(), self._stream()))
+        return (obs if compute_obs else None), rewards, terminated, truncated, {"is_active": is_active}
+
+    # ------------------------------------------------------------------------------------------
+    def get_state(self, occupancy: bool = False):
+        B, A, r = self.batch, self.num_agents, self.obs_radius
+        dev = self.device
+        agents = torch.empty((B, A, 2), dtype=torch.int32, device=dev)
+        targets = torch.empty((B, A, 2), dtype=torch.int32, device=dev)
+        active = torch.empty((B, A), dtype=torch.bool, device=dev)
+        elapsed = torch.empty((B,), dtype=torch.int32, device=dev)
+        occ = torch.empty((B, self.height + 2 * r, self.width + 2 * r), dtype=torch.uint8, device=dev) if occupancy else None
+        _lib.check(self._lib.pgx_get_state(self._handle, agents.data_ptr(), targets.data_ptr(), active.data_ptr(),
+                                           elapsed.data_ptr(), occ.data_ptr() if occupancy else None, self._stream()))
+        state = {"agents_xy": agents, "targets_xy": targets, "is_active": active, "elapsed": elapsed}
+        if occupancy:
+            state["occupancy"] = occ
+        return state

@@ -1,0 +1,119 @@
+"""Shared helpers for the parity tests: run one seeded scenario through the CPU oracle (test
+infrastructure, oracle/) and through the HIP engine (pogema_amd, via the C-ABI) and compare."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle.pogema_oracle import PogemaOracle  # noqa: E402
+
+
+def generate_instances(batch, height, width, num_agents, density, seed):
+    """Instances from the engine's HOST generator (pure host code; needs no GPU)."""
+    from pogema_amd import _lib
+    lib = _lib.load()
+    obstacles = np.empty((batch, height, width), dtype=np.uint8)
+    agents = np.empty((batch, num_agents, 2), dtype=np.int32)
+    targets = np.empty((batch, num_agents, 2), dtype=np.int32)
+    _lib.check(lib.pgx_generate(batch, height, width, num_agents, float(density), int(seed), 50, 0,
+                                obstacles.ctypes.data, agents.ctypes.data, targets.ctypes.data))
+    return obstacles, agents, targets
+
+
+def random_actions(steps, batch, num_agents, seed, p_noop=0.2):
+    rng = np.random.default_rng(seed)
+    a = rng.integers(1, 5, size=(steps, batch, num_agents))
+    a[rng.random(a.shape) < p_noop] = 0
+    return a.astype(np.int64)
+
+
+def oracle_rollout(obstacles, agents, targets, actions, *, obs_radius, collision_system, on_target,
+                   max_episode_steps, auto_reset, seed=0, env_index_base=0):
+    """Returns dict of arrays [T, B, ...] from the pure-Python oracle."""
+    T, B, A = actions.shape
+    W = 2 * obs_radius + 1
+    envs = [PogemaOracle(obstacles[b], agents[b], targets[b], obs_radius=obs_radius,
+                         collision_system=collision_system, on_target=on_target,
+                         max_episode_steps=max_episode_steps, auto_reset=auto_reset, seed=seed,
+                         env_index=env_index_base + b) for b in range(B)]
+    out = {
+        "obs0": np.stack([np.stack(e._obs()) for e in envs]),
+        "obs": np.zeros((T, B, A, 3, W, W), np.float32), "rewards": np.zeros((T, B, A), np.float32),
+        "terminated": np.zeros((T, B, A), bool), "truncated": np.zeros((T, B, A), bool),
+        "is_active": np.zeros((T, B, A), bool), "agents_xy": np.zeros((T, B, A, 2), np.int32),
+        "targets_xy": np.zeros((T, B, A, 2), np.int32), "elapsed": np.zeros((T, B), np.int32),
+    }
+    for t in range(T):
+        for b, e in enumerate(envs):
+            obs, rew, term, trunc, infos = e.step(actions[t, b])
+            out["obs"][t, b] = np.stack(obs)
+            out["rewards"][t, b] = rew
+            out["terminated"][t, b] = term
+            out["truncated"][t, b] = trunc
+            out["is_active"][t, b] = [i["is_active"] for i in infos]
+            st = e.get_state()
+            out["agents_xy"][t, b] = st["agents_xy"]
+            out["targets_xy"][t, b] = st["targets_xy"]
+            out["elapsed"][t, b] = st["elapsed"]
+    return out
+
+
+def engine_rollout(obstacles, agents, targets, actions, *, obs_radius, collision_system, on_target,
+                   max_episode_steps, auto_reset, seed=0, env_index_base=0, action_dtype="int64",
+                   device="cuda:0"):
+    """Same rollout through the HIP engine (C-ABI via pogema_amd.VecPogema)."""
+    import torch
+    from pogema_amd import GridConfig, VecPogema
+    T, B, A = actions.shape
+    H, Wd = obstacles.shape[1:]
+    gc = GridConfig(map=obstacles[0].tolist(), num_agents=A, obs_radius=obs_radius,
+                    collision_system=collision_system, on_target=on_target, max_episode_steps=max_episode_steps,
+                    seed=seed)
+    env = VecPogema(gc, batch=B, device=device, auto_reset=auto_reset, env_index_base=env_index_base)
+    obs0 = env.reset_from_state(obstacles, agents, targets)
+    W = 2 * obs_radius + 1
+    out = {
+        "obs0": obs0.cpu().numpy(),
+        "obs": np.zeros((T, B, A, 3, W, W), np.float32), "rewards": np.zeros((T, B, A), np.float32),
+        "terminated": np.zeros((T, B, A), bool), "truncated": np.zeros((T, B, A), bool),
+        "is_active": np.zeros((T, B, A), bool), "agents_xy": np.zeros((T, B, A, 2), np.int32),
+        "targets_xy": np.zeros((T, B, A, 2), np.int32), "elapsed": np.zeros((T, B), np.int32),
+    }
+    tdt = {"int8": torch.int8, "int32": torch.int32, "int64": torch.int64}[action_dtype]
+    d_actions = torch.from_numpy(actions).to(device).to(tdt)
+    for t in range(T):
+        obs, rew, term, trunc, infos = env.step(d_actions[t])
+        st = env.get_state()
+        out["obs"][t] = obs.cpu().numpy()
+        out["rewards"][t] = rew.cpu().numpy()
+        out["terminated"][t] = term.cpu().numpy()
+        out["truncated"][t] = trunc.cpu().numpy()
+        out["is_active"][t] = infos["is_active"].cpu().numpy()
+        out["agents_xy"][t] = st["agents_xy"].cpu().numpy()
+        out["targets_xy"][t] = st["targets_xy"].cpu().numpy()
+        out["elapsed"][t] = st["elapsed"].cpu().numpy()
+    env.close()
+    return out
+
+
+def assert_rollouts_equal(ref, got, what=""):
+    """Bit-exact for every integer/bool/index field and for the 0.0/1.0 float planes; rewards within
+    1e-6 (BASELINE.json north_star tolerance)."""
+    for key in ("agents_xy", "targets_xy", "elapsed", "terminated", "truncated", "is_active"):
+        if not np.array_equal(ref[key], got[key]):
+            bad = np.argwhere(ref[key] != got[key])[0]
+            raise AssertionError(f"{what}: {key} differs first at index {tuple(bad)}: "
+                                 f"oracle={ref[key][tuple(bad)]} engine={got[key][tuple(bad)]}")
+    np.testing.assert_allclose(got["rewards"], ref["rewards"], rtol=0, atol=1e-6, err_msg=f"{what}: rewards")
+    for key in ("obs0", "obs"):
+        if not np.array_equal(ref[key], got[key]):
+            bad = np.argwhere(ref[key] != got[key])[0]
+            raise AssertionError(f"{what}: {key} differs first at index {tuple(bad)}: "
+                                 f"oracle={ref[key][tuple(bad)]} engine={got[key][tuple(bad)]}")

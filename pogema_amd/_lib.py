@@ -54,6 +54,10 @@ def load() -> C.CDLL:
         return _lib
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} not found: the HIP engine is not built; {build_hint()}")
+    # torch ships its own libamdhip64.so.7; load it FIRST so that the dynamic loader resolves our
+    # NEEDED libamdhip64.so.7 to the very same runtime (two HIP runtimes in one process cannot both
+    # own the GPU: the second reports "no ROCm-capable device").
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64, u64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
     lib.pgx_abi_version.restype = C.c_int

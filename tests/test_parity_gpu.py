@@ -21,8 +21,8 @@ GEOMETRIES = [
     ("one_agent", 70, 5, 5, 1, 1, 0.2, 12, 8),           # G=1: 64 envs per wave + ragged tail
     ("full_wave", 3, 12, 12, 64, 5, 0.15, 20, 64),       # G=64 exactly (configs[2] lane layout)
     ("odd_agents", 4, 9, 13, 37, 4, 0.1, 20, 10),        # rectangular map, A not a power of two
-    ("two_slots", 3, 14, 14, 100, 3, 0.1, 16, 8),        # K=2 (A > 64), ragged second slot
-    ("four_slots", 2, 20, 20, 256, 7, 0.15, 10, 6),      # K=4, configs[4] lane layout / radius
+    ("two_slots", 3, 18, 18, 100, 3, 0.1, 16, 8),         # K=2 (A > 64), ragged second slot
+    ("four_slots", 2, 27, 27, 256, 7, 0.1, 10, 6),       # K=4, configs[4] lane layout / radius
 ]
 
 

@@ -1,0 +1,104 @@
+"""CPU tests of the oracle itself (no GPU): the plain-C port must equal the literal Python
+restatement bit for bit, and both must reproduce the hand-derived SPEC vectors in tests/golden/."""
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from util import assert_rollouts_equal, c_oracle_rollout, generate_instances, oracle_rollout, random_actions
+
+COLLISIONS = ("priority", "block_both", "soft")
+ON_TARGET = ("finish", "restart", "nothing")
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+GEOMS = [
+    ("cfg0", 4, 8, 8, 2, 3, 0.3, 20, 8),
+    ("cfg1", 3, 16, 16, 8, 5, 0.3, 20, 8),
+    ("dense", 4, 6, 6, 14, 2, 0.1, 30, 10),
+    ("crowd", 2, 10, 10, 40, 4, 0.1, 25, 9),
+    ("rect", 3, 5, 11, 9, 1, 0.15, 20, 7),
+]
+
+
+@pytest.mark.parametrize("geom", GEOMS, ids=[g[0] for g in GEOMS])
+@pytest.mark.parametrize("collision", COLLISIONS)
+@pytest.mark.parametrize("on_target", ON_TARGET)
+def test_c_port_equals_python_oracle(geom, collision, on_target):
+    name, B, H, Wd, A, r, density, T, max_steps = geom
+    seed = zlib.crc32(f"{name}/{collision}/{on_target}".encode()) % (2 ** 31)
+    obstacles, agents, targets = generate_instances(B, H, Wd, A, density, seed)
+    actions = random_actions(T, B, A, seed + 1)
+    for auto_reset in (False, True):
+        kw = dict(obs_radius=r, collision_system=collision, on_target=on_target, max_episode_steps=max_steps,
+                  auto_reset=auto_reset, seed=77, env_index_base=3)
+        ref = oracle_rollout(obstacles, agents, targets, actions, **kw)
+        got = c_oracle_rollout(obstacles, agents, targets, actions, **kw)
+        assert_rollouts_equal(ref, got, f"{name}/{collision}/{on_target}/{auto_reset}")
+
+
+def test_c_port_threads_deterministic():
+    B, H, Wd, A, r = 16, 12, 12, 20, 3
+    obstacles, agents, targets = generate_instances(B, H, Wd, A, 0.2, 4)
+    actions = random_actions(10, B, A, 9)
+    kw = dict(obs_radius=r, collision_system="soft", on_target="restart", max_episode_steps=6, auto_reset=True)
+    a = c_oracle_rollout(obstacles, agents, targets, actions, nthreads=1, **kw)
+    b = c_oracle_rollout(obstacles, agents, targets, actions, nthreads=4, **kw)
+    assert_rollouts_equal(a, b, "threads")
+
+
+def _load_spec_vectors():
+    with open(os.path.join(GOLDEN, "spec_vectors.json")) as f:
+        return json.load(f)["cases"]
+
+
+@pytest.mark.parametrize("case", _load_spec_vectors(), ids=lambda c: c["name"])
+@pytest.mark.parametrize("impl", ["python", "c"])
+def test_spec_vectors(case, impl):
+    """Hand-derived expectations (SURVEY section 8a SPEC column) -- NOT outputs of the reference."""
+    obstacles = np.array(case["map"], np.uint8)[None]
+    agents = np.array(case["agents_xy"], np.int32)[None]
+    targets = np.array(case["targets_xy"], np.int32)[None]
+    actions = np.array(case["actions"], np.int64)[:, None, :]
+    kw = dict(obs_radius=case["obs_radius"], collision_system=case["collision_system"], on_target=case["on_target"],
+              max_episode_steps=case.get("max_episode_steps", 64), auto_reset=False)
+    run = oracle_rollout if impl == "python" else c_oracle_rollout
+    out = run(obstacles, agents, targets, actions, **kw)
+    exp = case["expect"]
+    assert out["agents_xy"][:, 0].tolist() == exp["agents_xy"], case["why"]
+    if "rewards" in exp:
+        assert out["rewards"][:, 0].tolist() == exp["rewards"]
+    if "terminated" in exp:
+        assert out["terminated"][:, 0].astype(int).tolist() == exp["terminated"]
+    if "truncated" in exp:
+        assert out["truncated"][:, 0].astype(int).tolist() == exp["truncated"]
+    if "is_active" in exp:
+        assert out["is_active"][:, 0].astype(int).tolist() == exp["is_active"]
+    if "obs0_agent0" in exp:
+        assert out["obs0"][0, 0].astype(int).tolist() == exp["obs0_agent0"]
+
+
+def test_observation_planes_by_hand():
+    """A9/A10/A11 on a 3x3 map with r=2: border ring, occupancy incl. self, clamped target."""
+    from oracle.pogema_oracle import PogemaOracle
+    obstacles = np.zeros((3, 3), np.uint8)
+    obstacles[0, 1] = 1
+    env = PogemaOracle(obstacles, [(1, 1), (2, 2)], [(1, 1 + 1), (0, 0)], obs_radius=2)
+    obs = env._obs()
+    # agent 0 at the map centre: window covers the whole padded 7x7 minus one ring -> 5x5
+    exp_obst = np.array([[1, 1, 1, 1, 1], [1, 0, 1, 0, 1], [1, 0, 0, 0, 1], [1, 0, 0, 0, 1], [1, 1, 1, 1, 1]], np.float32)
+    assert np.array_equal(obs[0][0], exp_obst)
+    exp_pos = np.zeros((5, 5), np.float32)
+    exp_pos[2, 2] = 1  # self
+    exp_pos[3, 3] = 1  # agent 1
+    assert np.array_equal(obs[0][1], exp_pos)
+    exp_tgt = np.zeros((5, 5), np.float32)
+    exp_tgt[2, 3] = 1  # target one cell to the right
+    assert np.array_equal(obs[0][2], exp_tgt)
+    # agent 1 at (2,2), target (0,0): offset (2,2) -> window cell (r-2, r-2) = (0, 0)
+    assert obs[1][2][0, 0] == 1 and obs[1][2].sum() == 1
+    # clamping: r=1 window for the same geometry puts the far target on the window corner
+    env1 = PogemaOracle(obstacles, [(2, 2)], [(0, 0)], obs_radius=1)
+    t = env1._obs()[0][2]
+    assert t[0, 0] == 1 and t.sum() == 1

@@ -65,6 +65,32 @@ def oracle_rollout(obstacles, agents, targets, actions, *, obs_radius, collision
     return out
 
 
+def c_oracle_rollout(obstacles, agents, targets, actions, *, obs_radius, collision_system, on_target,
+                     max_episode_steps, auto_reset, seed=0, env_index_base=0, nthreads=1):
+    """Same rollout through the plain-C oracle port (oracle/libpogema_oracle.so)."""
+    from oracle.c_oracle import COracle
+    T, B, A = actions.shape
+    H, Wd = obstacles.shape[1:]
+    W = 2 * obs_radius + 1
+    env = COracle(B, H, Wd, A, obs_radius, collision_system, on_target, max_episode_steps, auto_reset, seed,
+                  env_index_base)
+    out = {
+        "obs0": env.reset(obstacles, agents, targets),
+        "obs": np.zeros((T, B, A, 3, W, W), np.float32), "rewards": np.zeros((T, B, A), np.float32),
+        "terminated": np.zeros((T, B, A), bool), "truncated": np.zeros((T, B, A), bool),
+        "is_active": np.zeros((T, B, A), bool), "agents_xy": np.zeros((T, B, A, 2), np.int32),
+        "targets_xy": np.zeros((T, B, A, 2), np.int32), "elapsed": np.zeros((T, B), np.int32),
+    }
+    for t in range(T):
+        obs, rew, term, trunc, act = env.step(actions[t], nthreads=nthreads)
+        st = env.get_state()
+        out["obs"][t], out["rewards"][t], out["terminated"][t], out["truncated"][t] = obs, rew, term, trunc
+        out["is_active"][t] = act
+        out["agents_xy"][t], out["targets_xy"][t], out["elapsed"][t] = st["agents_xy"], st["targets_xy"], st["elapsed"]
+    env.close()
+    return out
+
+
 def engine_rollout(obstacles, agents, targets, actions, *, obs_radius, collision_system, on_target,
                    max_episode_steps, auto_reset, seed=0, env_index_base=0, action_dtype="int64",
                    device="cuda:0"):

@@ -1,0 +1,97 @@
+"""Writes tests/golden/spec_vectors.json: HAND-DERIVED known-answer cases for the step path.
+
+These are NOT outputs of the reference (which is not available in this container: /root/reference
+holds only README.md) and NOT outputs of the oracle either -- every expectation below was worked out
+by hand from SURVEY.md section 8a (rows A2..A13) and is stated with its reasoning in `why`, so the
+oracle (tests/test_oracle.py) and the HIP engine (tests/test_spec_vectors_gpu.py) are both checked
+against something neither of them produced.  When a real `pogema` checkout becomes importable,
+tools/gen_golden.py replaces/extends these with true reference vectors.
+"""
+import json
+import os
+
+OPEN3 = [[0, 0, 0], [0, 0, 0], [0, 0, 0]]
+NOOP, UP, DOWN, LEFT, RIGHT = 0, 1, 2, 3, 4
+cases = []
+
+
+def case(name, why, map_, agents, targets, actions, collision, expect, on_target="finish", r=1, max_steps=64):
+    cases.append(dict(name=f"{name}-{collision}", why=why, map=map_, agents_xy=agents, targets_xy=targets,
+                      actions=actions, collision_system=collision, on_target=on_target, obs_radius=r,
+                      max_episode_steps=max_steps, expect=expect))
+
+
+far = [[2, 2], [2, 0]]
+# --- vertex conflict ------------------------------------------------------------------------------------
+case("vertex", "A3: agents move in index order; 0 takes (0,1) first, 1 then finds it occupied",
+     OPEN3, [[0, 0], [0, 2]], far, [[RIGHT, LEFT]], "priority",
+     dict(agents_xy=[[[0, 1], [0, 2]]],
+          obs0_agent0=[[[1, 1, 1], [1, 0, 0], [1, 0, 0]], [[0, 0, 0], [0, 1, 0], [0, 0, 0]], [[0, 0, 0], [0, 0, 0], [0, 0, 1]]]))
+case("vertex", "A4: a destination claimed twice is blocked for both", OPEN3, [[0, 0], [0, 2]], far,
+     [[RIGHT, LEFT]], "block_both", dict(agents_xy=[[[0, 0], [0, 2]]]))
+case("vertex", "A5 literal algorithm: the reverse-index loop reverts agent 1 first (2 claimants), which REMOVES it "
+     "from used_cells[(0,1)]; agent 0 is then the sole claimant and moves (open parity question 1 in DESIGN.md)",
+     OPEN3, [[0, 0], [0, 2]], far, [[RIGHT, LEFT]], "soft", dict(agents_xy=[[[0, 1], [0, 2]]]))
+# --- edge swap ------------------------------------------------------------------------------------------
+for cs, why in (("priority", "A3: each finds the other's cell occupied at its turn"),
+                ("block_both", "A4: every currently occupied cell is blocked"),
+                ("soft", "A5: edge (swap) conflict reverts both")):
+    case("swap", why, OPEN3, [[0, 0], [0, 1]], far, [[RIGHT, LEFT]], cs, dict(agents_xy=[[[0, 0], [0, 1]]]))
+# --- following ------------------------------------------------------------------------------------------
+case("follow_lower_leads", "A3: agent 0 vacates (0,1) before agent 1's turn, so 1 may enter it",
+     OPEN3, [[0, 1], [0, 0]], far, [[RIGHT, RIGHT]], "priority", dict(agents_xy=[[[0, 2], [0, 1]]]))
+case("follow_lower_leads", "A4: (0,1) is an agent's current cell -> blocked; the leader's own move is free",
+     OPEN3, [[0, 1], [0, 0]], far, [[RIGHT, RIGHT]], "block_both", dict(agents_xy=[[[0, 2], [0, 0]]]))
+case("follow_lower_leads", "A5: following is allowed", OPEN3, [[0, 1], [0, 0]], far, [[RIGHT, RIGHT]], "soft",
+     dict(agents_xy=[[[0, 2], [0, 1]]]))
+case("follow_higher_leads", "A3: at agent 0's turn agent 1 has not moved yet -> 0 is blocked; 1 then moves",
+     OPEN3, [[0, 0], [0, 1]], far, [[RIGHT, RIGHT]], "priority", dict(agents_xy=[[[0, 0], [0, 2]]]))
+case("follow_higher_leads", "A4: as above, follower blocked", OPEN3, [[0, 0], [0, 1]], far, [[RIGHT, RIGHT]],
+     "block_both", dict(agents_xy=[[[0, 0], [0, 2]]]))
+case("follow_higher_leads", "A5: order-independent following", OPEN3, [[0, 0], [0, 1]], far, [[RIGHT, RIGHT]],
+     "soft", dict(agents_xy=[[[0, 1], [0, 2]]]))
+# --- 2x2 rotation -----------------------------------------------------------------------------------------
+rot_agents = [[0, 0], [0, 1], [1, 1], [1, 0]]
+rot_targets = [[2, 2], [2, 1], [2, 0], [0, 2]]
+rot_actions = [[RIGHT, DOWN, LEFT, UP]]
+case("rotation", "A3: every destination is occupied at the mover's turn", OPEN3, rot_agents, rot_targets, rot_actions,
+     "priority", dict(agents_xy=[rot_agents]))
+case("rotation", "A4: all destinations are currently occupied cells", OPEN3, rot_agents, rot_targets, rot_actions,
+     "block_both", dict(agents_xy=[rot_agents]))
+case("rotation", "A5: cyclic rotation is allowed (one claimant per cell, no swap edge)", OPEN3, rot_agents, rot_targets,
+     rot_actions, "soft", dict(agents_xy=[[[0, 1], [1, 1], [1, 0], [0, 0]]]))
+# --- obstacles, border ring, cascade --------------------------------------------------------------------------
+ROW = [[0, 0, 0, 1]]
+for cs in ("priority", "block_both", "soft"):
+    case("blocked_chain", "front agent faces an obstacle; under every system nobody behind it can advance "
+         "(A3: occupied at turn; A4: occupied cells blocked; A5: revert cascades down the chain)",
+         ROW, [[0, 0], [0, 1], [0, 2]], [[0, 2], [0, 0], [0, 1]], [[RIGHT, RIGHT, RIGHT]], cs,
+         dict(agents_xy=[[[0, 0], [0, 1], [0, 2]]]))
+    case("border", "A1: the wall ring around the map blocks moves off the map", OPEN3, [[0, 0], [2, 2]], [[1, 1], [1, 0]],
+         [[UP, RIGHT], [LEFT, DOWN]], cs, dict(agents_xy=[[[0, 0], [2, 2]], [[0, 0], [2, 2]]]))
+case("stayer_wins", "A5: a noop agent keeps its cell; the mover into it is reverted and so is the one following it",
+     OPEN3, [[0, 0], [0, 1], [0, 2]], [[2, 2], [2, 1], [2, 0]], [[NOOP, LEFT, LEFT]], "soft",
+     dict(agents_xy=[[[0, 0], [0, 1], [0, 2]]]))
+case("three_way", "A5 literal: three movers claim (1,1); reverse-index reverts 2 then 1, agent 0 remains sole claimant; "
+     "agent 3 follows the reverted agent 2 and is reverted by the cascade",
+     [[0, 0, 0, 0], [0, 0, 0, 0], [0, 0, 0, 0]], [[0, 1], [1, 0], [1, 2], [1, 3]], [[2, 3], [2, 2], [2, 1], [2, 0]],
+     [[DOWN, RIGHT, LEFT, LEFT]], "soft", dict(agents_xy=[[[1, 1], [1, 0], [1, 2], [1, 3]]]))
+# --- goals / hide / time limit / cooperative finish ------------------------------------------------------------
+case("finish_hide", "A6: reward once on arrival, terminated stays true, the finished agent is hidden so another agent "
+     "may enter its cell; A2 noop keeps position",
+     OPEN3, [[0, 0], [0, 2]], [[0, 1], [2, 2]], [[RIGHT, NOOP], [RIGHT, LEFT]], "priority",
+     dict(agents_xy=[[[0, 1], [0, 2]], [[0, 1], [0, 1]]], rewards=[[1.0, 0.0], [0.0, 0.0]],
+          terminated=[[1, 0], [1, 0]], is_active=[[0, 1], [0, 1]], truncated=[[0, 0], [0, 0]]))
+case("time_limit", "A13: truncated for all agents once elapsed >= max_episode_steps", OPEN3, [[0, 0], [2, 2]],
+     [[1, 1], [1, 0]], [[NOOP, NOOP], [NOOP, NOOP], [NOOP, NOOP]], "priority",
+     dict(agents_xy=[[[0, 0], [2, 2]]] * 3, truncated=[[0, 0], [1, 1], [1, 1]], terminated=[[0, 0]] * 3), max_steps=2)
+case("coop_finish", "A8: nothing happens on a goal until ALL agents stand on theirs; then everyone gets 1.0 and terminates",
+     OPEN3, [[0, 0], [2, 2]], [[0, 1], [2, 0]], [[RIGHT, LEFT], [NOOP, LEFT]], "priority",
+     dict(agents_xy=[[[0, 1], [2, 1]], [[0, 1], [2, 0]]], rewards=[[0.0, 0.0], [1.0, 1.0]], terminated=[[0, 0], [1, 1]],
+          is_active=[[1, 1], [1, 1]]), on_target="nothing")
+
+out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "spec_vectors.json")
+with open(out, "w") as f:
+    json.dump(dict(provenance="hand-derived from SURVEY.md section 8a; NOT reference outputs (reference unavailable)",
+                   cases=cases), f, indent=1)
+print(len(cases), "cases ->", out)

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -69,11 +70,15 @@ struct pgx_env {
     int W = 0, PH = 0, PW = 0, wpr = 0, bmw = 0;
     size_t lds_bytes = 0;
     bool has_state = false;
+    bool p16 = false;
+    uint32_t flags = 0;
     // device state
     uint32_t* obst = nullptr;
     uint32_t *pos = nullptr, *tgt = nullptr, *pos0 = nullptr, *tgt0 = nullptr;
     uint8_t* active = nullptr;
     int32_t* elapsed = nullptr;
+    unsigned long long* dbg = nullptr;
+    size_t dbg_elems = 0;
     uint32_t *comp_begin = nullptr, *comp_len = nullptr, *comp_cells = nullptr, *tcount = nullptr;
 };
 
@@ -118,7 +123,9 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
         e->K = std::max(2, next_pow2((A + 63) / 64));
         e->G = 64;
     }
-    e->lds_bytes = pgx::step_lds_bytes(e->K, e->G, A, e->bmw, e->W);
+    if (const char* f = getenv("PGX_FLAGS")) e->flags = (uint32_t)strtoul(f, nullptr, 0);
+    e->p16 = pgx::step_uses_p16(e->K, e->W) && !(e->flags & 2u);  // PGX_FLAGS bit1: force the generic path
+    e->lds_bytes = pgx::step_lds_bytes(e->K, e->G, A, e->bmw, e->W, e->p16);
     if (e->lds_bytes > 160 * 1024) {
         const size_t need = e->lds_bytes;
         delete e;
@@ -157,6 +164,12 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
         pgx_destroy(e);
         return fail(err == hipErrorOutOfMemory ? PGX_E_NOMEM : PGX_E_HIP, "hipMalloc failed: %s", msg);
     }
+    if (const char* f = getenv("PGX_FLAGS")) e->flags = (uint32_t)strtoul(f, nullptr, 0);
+    if (e->flags & 4u) {  // diagnostic time stamps, one record per workgroup
+        e->dbg_elems = (size_t)cfg->batch * 4;
+        if (hipMalloc((void**)&e->dbg, e->dbg_elems * sizeof(unsigned long long)) != hipSuccess) e->dbg = nullptr;
+        else (void)hipMemset(e->dbg, 0, e->dbg_elems * sizeof(unsigned long long));
+    }
     *out = e;
     return PGX_OK;
 }
@@ -165,7 +178,7 @@ int pgx_destroy(pgx_env* e) {
     if (!e) return PGX_OK;
     DeviceGuard guard(e->device);
     void* ptrs[] = {e->obst,   e->pos,     e->tgt,        e->pos0,     e->tgt0,       e->active,
-                    e->elapsed, e->comp_begin, e->comp_len, e->comp_cells, e->tcount};
+                    e->elapsed, e->comp_begin, e->comp_len, e->comp_cells, e->tcount, e->dbg};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete e;
@@ -282,6 +295,7 @@ static void fill_params(const pgx_env* e, pgx::StepParams& p) {
     p.on_target = c.on_target;
     p.max_steps = c.max_episode_steps;
     p.auto_reset = c.auto_reset;
+    p.flags = e->flags;
     p.seed = c.seed;
     p.env_index_base = c.env_index_base;
     p.obst = e->obst;
@@ -295,6 +309,7 @@ static void fill_params(const pgx_env* e, pgx::StepParams& p) {
     p.comp_len = e->comp_len;
     p.comp_cells = e->comp_cells;
     p.tcount = e->tcount;
+    p.dbg = e->dbg;
 }
 
 int pgx_step(pgx_env* e, const void* actions, int action_dtype, float* obs, float* rewards, uint8_t* terminated,
@@ -314,7 +329,7 @@ int pgx_step(pgx_env* e, const void* actions, int action_dtype, float* obs, floa
     p.terminated = terminated;
     p.truncated = truncated;
     p.act_out = is_active;
-    PGX_HIP(pgx::launch_step(p, e->K, e->G, e->lds_bytes, (hipStream_t)stream));
+    PGX_HIP(pgx::launch_step(p, e->K, e->G, e->p16, e->lds_bytes, (hipStream_t)stream));
     return PGX_OK;
 }
 
@@ -327,7 +342,7 @@ int pgx_observe(pgx_env* e, float* obs, void* stream) {
     fill_params(e, p);
     p.mode = pgx::MODE_OBSERVE;
     p.obs = obs;
-    PGX_HIP(pgx::launch_step(p, e->K, e->G, e->lds_bytes, (hipStream_t)stream));
+    PGX_HIP(pgx::launch_step(p, e->K, e->G, e->p16, e->lds_bytes, (hipStream_t)stream));
     return PGX_OK;
 }
 
@@ -348,6 +363,18 @@ int pgx_get_state(pgx_env* e, int32_t* agent_xy, int32_t* target_xy, uint8_t* is
         PGX_HIP(pgx::launch_occupancy(e->pos, e->active, occupancy, BA, c.num_agents, e->PH, e->PW, s));
     }
     return PGX_OK;
+}
+
+// Diagnostic only (not part of include/pogema_amd.h): copies the per-workgroup clock stamps of the last
+// launch to the host; needs PGX_FLAGS bit 2 at pgx_create.  Synchronises the device.
+int pgx_debug_timestamps(pgx_env* e, unsigned long long* host_out, int64_t max_elems) {
+    if (!e || !host_out) return fail(PGX_E_INVALID, "pgx_debug_timestamps: null argument");
+    if (!e->dbg) return fail(PGX_E_STATE, "diagnostic stamps not enabled (PGX_FLAGS bit 2)");
+    DeviceGuard guard(e->device);
+    PGX_HIP(hipDeviceSynchronize());
+    const size_t n = std::min<size_t>(e->dbg_elems, (size_t)max_elems);
+    PGX_HIP(hipMemcpy(host_out, e->dbg, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return (int)PGX_OK;
 }
 
 // ================================================================================================

@@ -21,6 +21,7 @@ struct StepParams {
     uint32_t w_magic;  // ceil(2^32 / (2r+1)): exact division of flat window offsets by the window side
     // behaviour
     int32_t mode, collision, on_target, max_steps, auto_reset, action_dtype;
+    uint32_t flags;    // tuning switches (PGX_FLAGS env var at pgx_create): bit0 = nontemporal obs stores
     uint64_t seed;
     int64_t env_index_base;
     // SoA state in HBM
@@ -43,10 +44,12 @@ struct StepParams {
     uint8_t* terminated;
     uint8_t* truncated;
     uint8_t* act_out;
+    unsigned long long* dbg;  // diagnostic (PGX_FLAGS bit2): per-workgroup {start, resolve done, first store, end} clocks
 };
 
-hipError_t launch_step(const StepParams& p, int K, int G, size_t lds_bytes, hipStream_t stream);
-size_t step_lds_bytes(int K, int G, int A, int bmw, int W);
+hipError_t launch_step(const StepParams& p, int K, int G, bool p16, size_t lds_bytes, hipStream_t stream);
+bool step_uses_p16(int K, int W);
+size_t step_lds_bytes(int K, int G, int A, int bmw, int W, bool p16);
 
 hipError_t launch_pack_obstacles(const uint8_t* obstacles, uint32_t* bm, int batch, int H, int Wd, int r,
                                  int wpr, int bmw, hipStream_t stream);

@@ -39,31 +39,42 @@ __device__ __forceinline__ uint32_t lifelong_draw(uint64_t seed, uint64_t env_in
     return (uint32_t)(((h >> 32) * (uint64_t)n) >> 32);
 }
 
-// packed cell: (x << 16) | y in PADDED coordinates; MOVES = noop, up, down, left, right with the
-// first index the row.
-__device__ __forceinline__ uint32_t apply_move(uint32_t cell, int a) {
-    const uint32_t delta = (a == 1) ? 0xFFFF0000u : (a == 2) ? 0x00010000u : (a == 3) ? 0xFFFFFFFFu
-                         : (a == 4) ? 0x00000001u : 0u;
-    return cell + delta;
-}
-
+// packed cell in HBM/LDS: (x << 16) | y in PADDED coordinates.
 __device__ __forceinline__ uint32_t bm_test(const uint32_t* bm, int wpr, uint32_t cell) {
     const uint32_t x = cell >> 16, y = cell & 0xFFFFu;
     return (bm[x * wpr + (y >> 5)] >> (y & 31)) & 1u;
 }
 
-constexpr uint32_t NOCELL_A = 0xFFFFFFFFu;  // "stands nowhere"   (hidden / invalid lane)
-constexpr uint32_t NOCELL_B = 0xFFFFFFFEu;  // "claims nothing"
+// ---- 22-bit cell keys -----------------------------------------------------------------------------
+// HBM/LDS hold cells as (x << 16) | y.  For the collision sweep they are re-packed to (x << 11) | y
+// (x, y < 2048) so that ((a ^ b) << 10) | index fits one 32-bit word: a single v_min_u32 then keeps
+// "the smallest index among exact matches" without any compare/select or scalar instruction.
+constexpr uint32_t NOCELL_A = 0x3FFFFFu;  // "stands nowhere"   (hidden / invalid lane)
+constexpr uint32_t NOCELL_B = 0x3FFFFEu;  // "claims nothing"
+constexpr uint32_t KEY_NONE = 0xFFFFFFFFu;
 
-// Broadcast of agent j's value to its environment group.
-//   G == 64 (one env per wave, incl. K > 1): j's lane is wave-uniform -> v_readlane_b32.
-//   G <  64: source lane differs per group -> ds_bpermute via __shfl.
+__device__ __forceinline__ uint32_t to_c22(uint32_t packed) { return ((packed >> 16) << 11) | (packed & 0x7FFu); }
+__device__ __forceinline__ uint32_t from_c22(uint32_t c) { return ((c >> 11) << 16) | (c & 0x7FFu); }
+__device__ __forceinline__ uint32_t move_c22(uint32_t c, int a) {
+    const uint32_t delta = (a == 1) ? (0u - 2048u) : (a == 2) ? 2048u : (a == 3) ? 0xFFFFFFFFu : (a == 4) ? 1u : 0u;
+    return c + delta;
+}
+
+// Rotate a value by one lane inside the environment group (lane i receives lane i+1's value, the last
+// lane of the group receives the first).  DPP where the hardware has a matching pattern, ds_bpermute
+// otherwise; applied cumulatively it walks every partner of the group in G-1 steps.
 template <int G>
-__device__ __forceinline__ uint32_t group_bcast(uint32_t v, int lj, int gbase) {
+__device__ __forceinline__ uint32_t rot1(uint32_t v, int src_lane) {
     if constexpr (G == 64) {
-        return (uint32_t)__builtin_amdgcn_readlane((int)v, lj);
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x134 /* wave_rol:1 */, 0xF, 0xF, false);
+    } else if constexpr (G == 16) {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x12F /* row_ror:15 */, 0xF, 0xF, false);
+    } else if constexpr (G == 4) {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x39 /* quad_perm:[1,2,3,0] */, 0xF, 0xF, false);
+    } else if constexpr (G == 2) {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, false);
     } else {
-        return (uint32_t)__shfl((int)v, gbase + lj, 64);
+        return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v);
     }
 }
 
@@ -74,19 +85,92 @@ __device__ __forceinline__ bool group_any(bool pred, int gbase) {
     if constexpr (G == 64) {
         return m != 0ull;
     } else {
-        constexpr unsigned long long gm = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
+        constexpr unsigned long long gm = (1ull << G) - 1ull;
         return ((m >> gbase) & gm) != 0ull;
     }
 }
 
-template <int G>
-__device__ __forceinline__ bool group_all(bool pred, int gbase, unsigned long long validmask) {
-    // all over the lanes selected by validmask (bits relative to the group)
-    const unsigned long long m = __ballot(pred);
-    if constexpr (G == 64) {
-        return (m & validmask) == validmask;
+// All-pairs sweep of one environment group, branch-free and VALU-only.  For every own agent i
+// (slot s) it min-reduces over all OTHER agents j of the environment:
+//   okey = ((vis_j ^ want_i) << 10) | j              -> okey < 1024  <=> some agent stands on want_i,
+//                                                       and okey is then that agent's index
+//   ckey = ((claim_j ^ want_i) << 10) | ((i-1-j)&1023) -> ckey < 1024 <=> some other agent claims want_i;
+//                                                       ckey < i     <=> a LOWER-index one does, and
+//                                                       i-1-ckey is the largest such index
+template <int K, int G>
+__device__ __forceinline__ void pair_sweep(const uint32_t (&vis)[K], const uint32_t (&claim)[K],
+                                           const uint32_t (&want)[K], int alane, int gbase, int A,
+                                           uint32_t (&okey)[K], uint32_t (&ckey)[K]) {
+#pragma unroll
+    for (int s = 0; s < K; ++s) okey[s] = ckey[s] = KEY_NONE;
+    const int src = gbase + ((alane + 1) & (G - 1));
+#pragma unroll
+    for (int sj = 0; sj < K; ++sj) {
+        if (sj * 64 >= A) break;  // uniform
+        uint32_t cr = vis[sj], dr = claim[sj];
+        if constexpr (K > 1) {  // k = 0: the same lane's agents in the other slots
+#pragma unroll
+            for (int s = 0; s < K; ++s) {
+                if (s == sj) continue;
+                const int i = s * 64 + alane, j = sj * 64 + alane;
+                okey[s] = min(okey[s], ((cr ^ want[s]) << 10) | (uint32_t)j);
+                ckey[s] = min(ckey[s], ((dr ^ want[s]) << 10) | (uint32_t)((i - 1 - j) & 1023));
+            }
+        }
+        for (int k = 1; k < G; ++k) {
+            cr = rot1<G>(cr, src);
+            dr = rot1<G>(dr, src);
+            const int j = sj * 64 + ((alane + k) & (G - 1));
+#pragma unroll
+            for (int s = 0; s < K; ++s) {
+                const int i = s * 64 + alane;
+                okey[s] = min(okey[s], ((cr ^ want[s]) << 10) | (uint32_t)j);
+                ckey[s] = min(ckey[s], ((dr ^ want[s]) << 10) | (uint32_t)((i - 1 - j) & 1023));
+            }
+        }
+    }
+}
+
+// value of agent idx[s] (same environment) for every own slot; idx < 0 -> `dflt`.
+template <int K, int G>
+__device__ __forceinline__ void group_gather(const uint32_t (&val)[K], const int (&idx)[K], uint32_t dflt, int alane,
+                                             int gbase, int A, uint32_t* s_xchg, uint32_t (&out)[K]) {
+    if constexpr (K == 1) {
+        const int src = gbase + (idx[0] < 0 ? alane : idx[0]);
+        const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)val[0]);
+        out[0] = idx[0] < 0 ? dflt : got;
     } else {
-        return ((m >> gbase) & validmask) == validmask;
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+            const int i = s * 64 + alane;
+            if (i < A) s_xchg[i] = val[s];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int s = 0; s < K; ++s) out[s] = (idx[s] >= 0) ? s_xchg[idx[s]] : dflt;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// Workgroup synchronisation that does NOT drain the vector-memory queue.  `__syncthreads()` makes
+// hipcc emit s_waitcnt vmcnt(0) first, i.e. the wave would sit on the acknowledgements of its own
+// state/flag stores -- microseconds under a saturated HBM write stream.  Only LDS traffic has to be
+// ordered here.  K == 1: the block is ONE wave, LDS operations of a wave execute in order, so a
+// compiler-level fence is enough (no s_barrier at all).
+template <int K>
+__device__ __forceinline__ void lds_sync() {
+    if constexpr (K == 1) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     }
 }
 
@@ -95,8 +179,13 @@ __device__ __forceinline__ bool group_all(bool pred, int gbase, unsigned long lo
 //   K == 1 : block = 1 wave, 64/G envs per block.
 //   K  > 1 : block = 4 waves, 1 env per block, G == 64; wave 0 resolves the moves.
 // ------------------------------------------------------------------------------------------------
-template <int K, int G>
+//   P16    : K == 1 and window side <= 16: row masks are packed to 16 bits, staged through registers
+//            and written OVER the (by then dead) bitmaps -> <= 5 KB of LDS per wave, so that all
+//            32 waves/CU are resident, every wave's loads are issued before the write stream starts
+//            and there is no drain tail (DESIGN.md "occupancy").
+template <int K, int G, bool P16>
 __global__ __launch_bounds__((K == 1) ? 64 : 256) void step_kernel(const StepParams p) {
+    static_assert(!P16 || K == 1, "P16 needs single-wave blocks");
     constexpr int NT = (K == 1) ? 64 : 256;
     constexpr int EPW = (K == 1) ? (64 / G) : 1;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -117,194 +206,147 @@ __global__ __launch_bounds__((K == 1) ? 64 : 256) void step_kernel(const StepPar
     uint32_t* s_apos = s_occ + EPW * bmw;       // [EPW*A]
     uint32_t* s_atgt = s_apos + EPW * A;        // [EPW*A]
     uint32_t* s_rows = s_atgt + EPW * A;        // [EPW*A*3*W + 1]
-    uint32_t* s_flag = s_rows + EPW * A * 3 * W + 1;  // [max(A,1)] soft-closure scratch (K > 1)
+    uint32_t* s_xchg = s_rows + EPW * A * 3 * W + 1;  // [max(A,1)] cross-lane exchange scratch (K > 1)
 
-    // ---- phase 1: stage obstacle bitmaps HBM -> LDS, clear the occupancy bitmaps ---------------
-    {
-        const uint32_t* g = p.obst + (size_t)env0 * bmw;
-        for (int i = tid; i < nenv * bmw; i += NT) {
-            s_obst[i] = g[i];
-            s_occ[i] = 0u;
-        }
-    }
-    __syncthreads();
+    const bool dbg = (p.flags & 4u) && p.dbg;
+    if (dbg && tid == 0) p.dbg[(size_t)blockIdx.x * 4 + 0] = wall_clock64();
+    // ---- phase 0: issue every global load of the step up front (one exposed HBM latency) ----------
+    const bool resolver = (K == 1) || (tid < 64);
+    const int env_l = (K == 1) ? (lane / G) : 0;
+    const int gbase = (K == 1) ? (lane & ~(G - 1)) : 0;
+    const int alane = (K == 1) ? (lane & (G - 1)) : lane;  // agent index within slot
+    const bool env_ok = env_l < nenv;
+    const int env = env0 + env_l;
 
-    // ---- phase 2: state update (wave 0) ---------------------------------------------------------
-    if (K == 1 || tid < 64) {
-        const int env_l = (K == 1) ? (lane / G) : 0;
-        const int gbase = (K == 1) ? (lane & ~(G - 1)) : 0;
-        const int alane = (K == 1) ? (lane & (G - 1)) : lane;  // agent index within slot
-        const bool env_ok = env_l < nenv;
-        const int env = env0 + env_l;
-        const uint32_t* obm = s_obst + env_l * bmw;
-
-        uint32_t pos[K], tgt[K], vis[K];
-        bool valid[K], active[K];
-        int act[K];
+    uint32_t pos[K], tgt[K];
+    bool valid[K], active[K];
+    int act[K];
+    int elapsed = 0;
+    if (resolver) {
 #pragma unroll
         for (int s = 0; s < K; ++s) {
             const int agent = s * 64 + alane;
             valid[s] = env_ok && agent < A;
             const size_t gi = (size_t)env * A + agent;
-            pos[s] = valid[s] ? p.pos[gi] : NOCELL_A;
-            tgt[s] = valid[s] ? p.tgt[gi] : NOCELL_B;
+            pos[s] = valid[s] ? p.pos[gi] : 0u;
+            tgt[s] = valid[s] ? p.tgt[gi] : 1u;
             active[s] = valid[s] ? (p.active[gi] != 0) : false;
             int a = 0;
             if (valid[s] && p.mode == MODE_STEP) {
                 if (p.action_dtype == 0) a = ((const int8_t*)p.actions)[gi];
                 else if (p.action_dtype == 1) a = ((const int32_t*)p.actions)[gi];
                 else a = (int)((const int64_t*)p.actions)[gi];
-                if (a < 0 || a > 4) a = 0;
             }
             act[s] = a;
-            vis[s] = active[s] ? pos[s] : NOCELL_A;
+        }
+        if (env_ok && p.mode == MODE_STEP) elapsed = p.elapsed[env];
+    }
+
+    // ---- phase 1: stage obstacle bitmaps HBM -> LDS, clear the occupancy bitmaps ---------------
+    {
+        const uint32_t* g = p.obst + (size_t)env0 * bmw;
+        const int n = nenv * bmw;
+#pragma unroll 4
+        for (int i = tid; i < n; i += NT) {
+            s_obst[i] = g[i];
+            s_occ[i] = 0u;
+        }
+    }
+    lds_sync<K>();
+
+    // ---- phase 2: state update (wave 0) ---------------------------------------------------------
+    if (resolver) {
+        const uint32_t* obm = s_obst + env_l * bmw;
+        uint32_t cur[K], vis[K];  // 22-bit keys: own cell / cell as seen by others (NOCELL_A when hidden)
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+            if (act[s] < 0 || act[s] > 4) act[s] = 0;
+            cur[s] = to_c22(pos[s]);
+            vis[s] = active[s] ? cur[s] : NOCELL_A;
         }
 
         if (p.mode == MODE_STEP) {
             // ================= move + collision resolve =========================================
-            if (p.collision == COLLISION_PRIORITY) {
-                // Sequential semantics: agent j moves iff its destination is free of
-                // obstacles and of agents AT ITS TURN (lower indices already moved).  The loop runs
-                // in agent-index order; occupancy lives in the `vis` registers of the group.
-                uint32_t dstm[K];  // bit31 = wants-to-move-legally, low bits = destination
+            // One all-pairs sweep gives, per agent: who stands on its destination (okey) and which
+            // other agents claim the same destination (ckey).  The three collision systems of the
+            // reference are closed-form functions of those two facts plus a transitive closure over
+            // "the agent in front of me does not move"; tests/test_parity_gpu.py proves each form
+            // equal to the literal sequential / dict-based algorithms of the oracle.
+            uint32_t want[K], okey[K], ckey[K];
+            bool mover[K], blocked[K];
+#pragma unroll
+            for (int s = 0; s < K; ++s) {
+                mover[s] = active[s] && act[s] != 0;
+                const uint32_t d = move_c22(cur[s], act[s]);
+                blocked[s] = mover[s] && bm_test(obm, wpr, from_c22(d));
+                // block_both registers a claim for every active agent (a noop claims its own cell)
+                const bool claims = (p.collision == COLLISION_BLOCK_BOTH) ? active[s] : mover[s];
+                want[s] = claims ? d : NOCELL_B;
+            }
+            pair_sweep<K, G>(vis, want, want, alane, gbase, A, okey, ckey);
+
+            bool stay[K];
+            int nxt[K];
+            if (p.collision == COLLISION_BLOCK_BOTH) {
+                // blocked <=> destination is someone's current cell or claimed twice.
 #pragma unroll
                 for (int s = 0; s < K; ++s) {
-                    const uint32_t d = apply_move(pos[s], act[s]);
-                    const bool mv = active[s] && act[s] != 0 && !bm_test(obm, wpr, d);
-                    dstm[s] = mv ? (d | 0x80000000u) : 0u;
-                }
-#pragma unroll
-                for (int sj = 0; sj < K; ++sj) {
-                    const int jn = min(64, A - sj * 64);
-                    const int jmax = (K == 1) ? min(G, A) : jn;
-                    for (int lj = 0; lj < jmax; ++lj) {
-                        const uint32_t dj = group_bcast<G>(dstm[sj], lj, gbase);
-                        if (G == 64 && dj == 0u) continue;  // wave-uniform skip
-                        const uint32_t d = dj & 0x7FFFFFFFu;
-                        bool hit = false;
-#pragma unroll
-                        for (int s = 0; s < K; ++s) hit |= (vis[s] == d);
-                        const bool occupied = group_any<G>(hit, gbase);
-                        if (dj != 0u && !occupied && alane == lj) {
-                            pos[sj] = d;
-                            vis[sj] = d;
-                        }
-                    }
-                }
-            } else if (p.collision == COLLISION_BLOCK_BOTH) {
-                // a destination is blocked if it is any active agent's current cell or is
-                // claimed by two agents (claims are made regardless of obstacles).
-                uint32_t raw[K];
-                bool conflict[K];
-#pragma unroll
-                for (int s = 0; s < K; ++s) {
-                    raw[s] = active[s] ? apply_move(pos[s], act[s]) : NOCELL_B;
-                    conflict[s] = false;
-                }
-#pragma unroll
-                for (int sj = 0; sj < K; ++sj) {
-                    const int jn = min(64, A - sj * 64);
-                    const int jmax = (K == 1) ? min(G, A) : jn;
-                    for (int lj = 0; lj < jmax; ++lj) {
-                        const uint32_t cj = group_bcast<G>(vis[sj], lj, gbase);
-                        const uint32_t dj = group_bcast<G>(raw[sj], lj, gbase);
-#pragma unroll
-                        for (int s = 0; s < K; ++s) {
-                            const bool self = (s == sj) && (alane == lj);
-                            conflict[s] |= !self && (raw[s] == cj || raw[s] == dj);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int s = 0; s < K; ++s) {
-                    if (active[s] && act[s] != 0 && !conflict[s] && !bm_test(obm, wpr, raw[s])) {
-                        pos[s] = raw[s];
-                        vis[s] = raw[s];
-                    }
-                }
-            } else {
-                // SURVEY A5 'soft'.  Net effect of the reference's dict/recursion algorithm, proven
-                // equal to it by tests/test_collision_equivalence.py (literal oracle vs this form):
-                //   agent i stays  <=>  noop | destination is an obstacle | edge swap with another
-                //   mover | a LOWER-index mover claims the same destination | the agent standing on
-                //   the destination stays (transitively).
-                uint32_t raw[K];
-                bool mover[K], stay[K];
-                int nxt[K];
-#pragma unroll
-                for (int s = 0; s < K; ++s) {
-                    mover[s] = active[s] && act[s] != 0;
-                    raw[s] = mover[s] ? apply_move(pos[s], act[s]) : NOCELL_B;
-                    stay[s] = !mover[s] || bm_test(obm, wpr, raw[s]);
+                    stay[s] = !mover[s] || blocked[s] || okey[s] < 1024u || ckey[s] < 1024u;
                     nxt[s] = -1;
                 }
-#pragma unroll
-                for (int sj = 0; sj < K; ++sj) {
-                    const int jn = min(64, A - sj * 64);
-                    const int jmax = (K == 1) ? min(G, A) : jn;
-                    for (int lj = 0; lj < jmax; ++lj) {
-                        const uint32_t cj = group_bcast<G>(vis[sj], lj, gbase);
-                        const uint32_t dj = group_bcast<G>(raw[sj], lj, gbase);  // NOCELL_B if not a mover
-                        const int j = sj * 64 + lj;
-#pragma unroll
-                        for (int s = 0; s < K; ++s) {
-                            const int i = s * 64 + alane;
-                            if (mover[s] && i != j) {
-                                if (cj == raw[s]) nxt[s] = j;                      // j stands on my destination
-                                if (dj == raw[s] && j < i) stay[s] = true;         // lower index wins the cell
-                                if (dj == pos[s] && cj == raw[s]) stay[s] = true;  // edge swap
-                            }
-                        }
-                    }
-                }
-                // transitive closure over "the agent on my destination stays": pointer doubling.
-                int rounds = 1;
-                while ((1 << rounds) < A) ++rounds;
-                if constexpr (K == 1) {
-                    int nx = nxt[0];
-                    bool st = stay[0];
-                    for (int it = 0; it < rounds; ++it) {
-                        const int src = gbase + (nx < 0 ? alane : nx);
-                        const int st_n = __shfl((int)st, src, 64);
-                        const int nx_n = __shfl(nx, src, 64);
-                        if (nx >= 0) {
-                            st = st || (st_n != 0);
-                            nx = nx_n;
-                        }
-                    }
-                    stay[0] = st;
-                } else {
-                    // A > 64: exchange through LDS (s_flag holds {stay bit31 | next+1}).
-                    for (int it = 0; it < rounds; ++it) {
-#pragma unroll
-                        for (int s = 0; s < K; ++s) {
-                            const int i = s * 64 + alane;
-                            if (i < A) s_flag[i] = (stay[s] ? 0x80000000u : 0u) | (uint32_t)(nxt[s] + 1);
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        uint32_t got[K];
-#pragma unroll
-                        for (int s = 0; s < K; ++s) got[s] = (nxt[s] >= 0) ? s_flag[nxt[s]] : 0u;
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-                        for (int s = 0; s < K; ++s) {
-                            if (nxt[s] >= 0) {
-                                stay[s] = stay[s] || (got[s] >> 31);
-                                nxt[s] = (int)(got[s] & 0x7FFFFFFFu) - 1;
-                            }
-                        }
-                    }
-                }
+            } else {
 #pragma unroll
                 for (int s = 0; s < K; ++s) {
-                    if (mover[s] && !stay[s]) {
-                        pos[s] = raw[s];
-                        vis[s] = raw[s];
+                    const int i = s * 64 + alane;
+                    const int o = okey[s] < 1024u ? (int)okey[s] : -1;           // agent on my destination
+                    const bool lower = ckey[s] < (uint32_t)i;                    // a lower index claims it too
+                    const int c1 = lower ? (i - 1 - (int)ckey[s]) : -1;          // the largest such index
+                    nxt[s] = mover[s] ? o : -1;
+                    if (p.collision == COLLISION_PRIORITY) {
+                        // SURVEY A3 (agents move one by one in index order).  Agent i ends up moving iff
+                        // its destination is free AT ITS TURN: the occupant o (if any) has a lower index
+                        // and moves away itself, and no claimant j with o < j < i got there first.
+                        stay[s] = !mover[s] || blocked[s] || o > i || c1 > o;
+                    } else {
+                        // SURVEY A5 'soft' (net effect of the dict/recursion algorithm): the lowest-index
+                        // claimant of a cell is the only candidate; edge swaps stay (resolved below).
+                        stay[s] = !mover[s] || blocked[s] || lower;
                     }
+                }
+                if (p.collision == COLLISION_SOFT) {
+                    uint32_t want_of_o[K];
+                    group_gather<K, G>(want, nxt, NOCELL_B, alane, gbase, A, s_xchg, want_of_o);
+#pragma unroll
+                    for (int s = 0; s < K; ++s) stay[s] = stay[s] || (want_of_o[s] == cur[s]);  // edge swap
+                }
+                // transitive closure of "the agent on my destination stays": pointer doubling, at most
+                // ceil(log2 A) rounds, usually 1-3 (exit as soon as every chain in the wave has ended).
+                int rounds = 1;
+                while ((1 << rounds) < A) ++rounds;
+                for (int it = 0; it < rounds; ++it) {
+                    bool open = false;
+#pragma unroll
+                    for (int s = 0; s < K; ++s) open = open || (nxt[s] >= 0 && !stay[s]);
+                    if (__ballot(open) == 0ull) break;
+                    uint32_t packed[K], got[K];
+#pragma unroll
+                    for (int s = 0; s < K; ++s) packed[s] = (stay[s] ? 0x80000000u : 0u) | (uint32_t)(nxt[s] + 1);
+                    group_gather<K, G>(packed, nxt, 0u, alane, gbase, A, s_xchg, got);
+#pragma unroll
+                    for (int s = 0; s < K; ++s) {
+                        if (nxt[s] >= 0) {
+                            stay[s] = stay[s] || (got[s] >> 31);
+                            nxt[s] = (int)(got[s] & 0x7FFFFFFFu) - 1;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < K; ++s) {
+                if (!stay[s]) {
+                    cur[s] = want[s];
+                    vis[s] = want[s];
+                    pos[s] = from_c22(want[s]);
                 }
             }
 
@@ -353,7 +395,6 @@ __global__ __launch_bounds__((K == 1) ? 64 : 256) void step_kernel(const StepPar
                 if (valid[s]) all_term_l = all_term_l && (term[s] != 0);
             }
             const bool all_term = !group_any<G>(!all_term_l, gbase);
-            int elapsed = env_ok ? p.elapsed[env] : 0;
             elapsed += 1;
             const bool trunc = p.max_steps > 0 && elapsed >= p.max_steps;
             const bool do_reset = p.auto_reset && (all_term || trunc);
@@ -370,7 +411,7 @@ __global__ __launch_bounds__((K == 1) ? 64 : 256) void step_kernel(const StepPar
                         pos[s] = p.pos0[gi];
                         tgt[s] = p.tgt0[gi];
                         active[s] = true;
-                        vis[s] = pos[s];
+                        vis[s] = to_c22(pos[s]);
                     }
                     p.pos[gi] = pos[s];
                     p.tgt[gi] = tgt[s];
@@ -389,15 +430,123 @@ __global__ __launch_bounds__((K == 1) ? 64 : 256) void step_kernel(const StepPar
                     s_apos[la] = pos[s];
                     s_atgt[la] = tgt[s];
                     if (vis[s] != NOCELL_A) {
-                        const uint32_t x = vis[s] >> 16, y = vis[s] & 0xFFFFu;
+                        const uint32_t x = pos[s] >> 16, y = pos[s] & 0xFFFFu;
                         atomicOr(&s_occ[env_l * bmw + x * wpr + (y >> 5)], 1u << (y & 31));
                     }
                 }
             }
         }
     }
+    if (dbg && tid == 0) p.dbg[(size_t)blockIdx.x * 4 + 1] = wall_clock64();
     if (!p.obs) return;
-    __syncthreads();
+    lds_sync<K>();
+
+    if constexpr (P16) {
+        // ---- phase 3 (P16): row masks -> registers -> (sync) -> packed u16 rows over the bitmaps -------
+        const uint32_t wmask = (1u << W) - 1u;
+        uint32_t rp[3][8];  // 16 rows x 16 bit per item, 3 items per lane (nag * 3 <= 192)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) rp[t][m] = 0u;
+            const int item = tid + t * 64;
+            if (item < nag * 3) {
+                const int la = item / 3;
+                const int c = item - la * 3;
+                const int el = la / A;
+                const uint32_t cell = s_apos[la];
+                const int x = (int)(cell >> 16), y = (int)(cell & 0xFFFFu);
+                if (c < 2) {
+                    const uint32_t* bm = (c == 0 ? s_obst : s_occ) + el * bmw;
+                    const int start = y - r;
+                    const int w0 = start >> 5, sh = start & 31;
+                    const bool two = (w0 + 1 < wpr);
+#pragma unroll
+                    for (int wy = 0; wy < 16; ++wy) {
+                        if (wy < W) {
+                            const uint32_t* rowp = bm + (x - r + wy) * wpr + w0;
+                            const uint32_t lo = rowp[0];
+                            const uint32_t hi = two ? rowp[1] : 0u;
+                            const uint32_t bits = (uint32_t)((((uint64_t)hi << 32) | lo) >> sh) & wmask;
+                            rp[t][wy >> 1] |= bits << (16 * (wy & 1));
+                        }
+                    }
+                } else {
+                    const uint32_t tc = s_atgt[la];
+                    int dx = x - (int)(tc >> 16), dy = y - (int)(tc & 0xFFFFu);
+                    dx = max(-r, min(r, dx));
+                    dy = max(-r, min(r, dy));
+                    const int hit = r - dx;
+                    const uint32_t val = (1u << (r - dy)) << (16 * (hit & 1));
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) rp[t][m] = (m == (hit >> 1)) ? val : 0u;
+                }
+            }
+        }
+        lds_sync<K>();  // every lane has read the bitmaps / agent cells: the region may be overwritten
+        uint16_t* rows16 = reinterpret_cast<uint16_t*>(smem);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int item = tid + t * 64;
+            if (item < nag * 3) {
+#pragma unroll
+                for (int wy = 0; wy < 16; ++wy)
+                    if (wy < W) rows16[item * W + wy] = (uint16_t)(rp[t][wy >> 1] >> (16 * (wy & 1)));
+            }
+        }
+        if (tid < 4) rows16[nag * 3 * W + tid] = 0;
+        lds_sync<K>();
+
+        // ---- phase 4 (P16): stream the float32 observations ----------------------------------------------
+        const int n = nag * 3 * W * W;
+        const size_t base = (size_t)env0 * A * 3 * W * W;
+        float* out = p.obs + base;
+        const int head = min(n, (int)((4 - (base & 3)) & 3));
+        const uint32_t magic = p.w_magic;
+        const int nvec = (n - head) >> 2;
+        const int tail0 = head + (nvec << 2);
+        if (tid < 8) {
+            const int e = (tid < 4) ? tid : tail0 + (tid - 4);
+            const bool mine = (tid < 4) ? (tid < head) : (e < n);
+            if (mine) {
+                const int row = (int)__umulhi((uint32_t)e, magic);
+                const int col = e - row * W;
+                out[e] = (float)((rows16[row] >> col) & 1u);
+            }
+        }
+        if (dbg && tid == 0) p.dbg[(size_t)blockIdx.x * 4 + 2] = wall_clock64();
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        f32x4* out4 = reinterpret_cast<f32x4*>(out + head);
+        const uint32_t* rows32 = smem;
+        // flat float offset e0 = head + 4q advances by 256 per iteration: keep (row, col) incrementally
+        int e0 = head + (tid << 2);
+        int row = (int)__umulhi((uint32_t)e0, magic);
+        int col = e0 - row * W;
+        const int drow = 256 / W, dcol = 256 - drow * W;
+        for (int q = tid; q < nvec; q += 64) {
+            const uint32_t w0 = rows32[row >> 1], w1 = rows32[(row >> 1) + 1];
+            const uint32_t pair = (uint32_t)((((uint64_t)w1 << 32) | w0) >> (16 * (row & 1)));  // row | row+1 << 16
+            const uint32_t b = ((pair & 0xFFFFu) >> col) | ((pair >> 16) << (W - col));
+            f32x4 v;
+            v.x = (float)(b & 1u);
+            v.y = (float)((b >> 1) & 1u);
+            v.z = (float)((b >> 2) & 1u);
+            v.w = (float)((b >> 3) & 1u);
+            if (p.flags & 1u) __builtin_nontemporal_store(v, &out4[q]);
+            else out4[q] = v;
+            col += dcol;
+            row += drow;
+            if (col >= W) {
+                col -= W;
+                row += 1;
+            }
+        }
+        if (dbg && tid == 0) {
+            __builtin_amdgcn_s_waitcnt(0);
+            p.dbg[(size_t)blockIdx.x * 4 + 3] = wall_clock64();
+        }
+        return;
+    }
 
     // ---- phase 3: one 32-bit mask per (agent, channel, window row) --------------------------------
     {
@@ -405,12 +554,12 @@ __global__ __launch_bounds__((K == 1) ? 64 : 256) void step_kernel(const StepPar
         for (int item = tid; item < nag * 3; item += NT) {
             const int la = item / 3;
             const int c = item - la * 3;
-            const int env_l = (K == 1) ? (la / A) : 0;
+            const int el = (K == 1) ? (la / A) : 0;
             const uint32_t cell = s_apos[la];
             const int x = (int)(cell >> 16), y = (int)(cell & 0xFFFFu);
             uint32_t* out = s_rows + item * W;
             if (c < 2) {
-                const uint32_t* bm = (c == 0 ? s_obst : s_occ) + env_l * bmw;
+                const uint32_t* bm = (c == 0 ? s_obst : s_occ) + el * bmw;
                 const int start = y - r;  // >= 0: agents live inside the padded interior
                 const int w0 = start >> 5, sh = start & 31;
                 for (int wy = 0; wy < W; ++wy) {
@@ -433,7 +582,7 @@ __global__ __launch_bounds__((K == 1) ? 64 : 256) void step_kernel(const StepPar
         }
         if (tid == 0) s_rows[nag * 3 * W] = 0u;
     }
-    __syncthreads();
+    lds_sync<K>();
 
     // ---- phase 4: stream the float32 observations, 16 bytes per lane per store ---------------------
     {
@@ -454,6 +603,7 @@ __global__ __launch_bounds__((K == 1) ? 64 : 256) void step_kernel(const StepPar
                 out[e] = (float)((s_rows[row] >> col) & 1u);
             }
         }
+        if (dbg && tid == 0) p.dbg[(size_t)blockIdx.x * 4 + 2] = wall_clock64();
         typedef float f32x4 __attribute__((ext_vector_type(4)));
         f32x4* out4 = reinterpret_cast<f32x4*>(out + head);
         for (int q = tid; q < nvec; q += NT) {
@@ -466,7 +616,12 @@ __global__ __launch_bounds__((K == 1) ? 64 : 256) void step_kernel(const StepPar
             v.y = (float)((b >> 1) & 1u);
             v.z = (float)((b >> 2) & 1u);
             v.w = (float)((b >> 3) & 1u);
-            __builtin_nontemporal_store(v, &out4[q]);
+            if (p.flags & 1u) __builtin_nontemporal_store(v, &out4[q]);
+            else out4[q] = v;
+        }
+        if (dbg && tid == 0) {
+            __builtin_amdgcn_s_waitcnt(0);  // stores retired (vmcnt 0) before the end stamp
+            p.dbg[(size_t)blockIdx.x * 4 + 3] = wall_clock64();
         }
     }
 }
@@ -555,46 +710,54 @@ __global__ void occupancy_kernel(const uint32_t* __restrict__ pos, const uint8_t
 // ------------------------------------------------------------------------------------------------
 // host-side launch helpers (called from pgx_api.cpp through pgx_internal.h)
 // ------------------------------------------------------------------------------------------------
-template <int K, int G>
+template <int K, int G, bool P16>
 static hipError_t launch_step_t(const StepParams& p, size_t lds_bytes, hipStream_t stream) {
     constexpr int NT = (K == 1) ? 64 : 256;
     constexpr int EPW = (K == 1) ? (64 / G) : 1;
     const int blocks = (p.batch + EPW - 1) / EPW;
     if (lds_bytes > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<K, G>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<K, G, P16>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((step_kernel<K, G>), dim3(blocks), dim3(NT), lds_bytes, stream, p);
+    hipLaunchKernelGGL((step_kernel<K, G, P16>), dim3(blocks), dim3(NT), lds_bytes, stream, p);
     return hipGetLastError();
 }
 
-hipError_t launch_step(const StepParams& p, int K, int G, size_t lds_bytes, hipStream_t stream) {
+hipError_t launch_step(const StepParams& p, int K, int G, bool p16, size_t lds_bytes, hipStream_t stream) {
     if (K == 1) {
+#define PGX_CASE(g)                                                        \
+    case g:                                                                \
+        return p16 ? launch_step_t<1, g, true>(p, lds_bytes, stream)       \
+                   : launch_step_t<1, g, false>(p, lds_bytes, stream);
         switch (G) {
-            case 1: return launch_step_t<1, 1>(p, lds_bytes, stream);
-            case 2: return launch_step_t<1, 2>(p, lds_bytes, stream);
-            case 4: return launch_step_t<1, 4>(p, lds_bytes, stream);
-            case 8: return launch_step_t<1, 8>(p, lds_bytes, stream);
-            case 16: return launch_step_t<1, 16>(p, lds_bytes, stream);
-            case 32: return launch_step_t<1, 32>(p, lds_bytes, stream);
-            case 64: return launch_step_t<1, 64>(p, lds_bytes, stream);
+            PGX_CASE(1) PGX_CASE(2) PGX_CASE(4) PGX_CASE(8) PGX_CASE(16) PGX_CASE(32) PGX_CASE(64)
             default: return hipErrorInvalidValue;
         }
+#undef PGX_CASE
     }
     switch (K) {
-        case 2: return launch_step_t<2, 64>(p, lds_bytes, stream);
-        case 4: return launch_step_t<4, 64>(p, lds_bytes, stream);
-        case 8: return launch_step_t<8, 64>(p, lds_bytes, stream);
-        case 16: return launch_step_t<16, 64>(p, lds_bytes, stream);
+        case 2: return launch_step_t<2, 64, false>(p, lds_bytes, stream);
+        case 4: return launch_step_t<4, 64, false>(p, lds_bytes, stream);
+        case 8: return launch_step_t<8, 64, false>(p, lds_bytes, stream);
+        case 16: return launch_step_t<16, 64, false>(p, lds_bytes, stream);
         default: return hipErrorInvalidValue;
     }
 }
 
-size_t step_lds_bytes(int K, int G, int A, int bmw, int W) {
+bool step_uses_p16(int K, int W) { return K == 1 && W <= 16; }
+
+size_t step_lds_bytes(int K, int G, int A, int bmw, int W, bool p16) {
     const int EPW = (K == 1) ? (64 / G) : 1;
-    size_t words = (size_t)2 * EPW * bmw + (size_t)2 * EPW * A + (size_t)EPW * A * 3 * W + 1 + (size_t)(A > 0 ? A : 1);
-    return ((words * 4) + 15) & ~(size_t)15;
+    const size_t state_words = (size_t)2 * EPW * bmw + (size_t)2 * EPW * A;  // bitmaps + agent cells
+    size_t bytes;
+    if (p16) {
+        const size_t rows_bytes = ((size_t)EPW * A * 3 * W + 4) * 2;  // u16 rows alias the state region
+        bytes = state_words * 4 > rows_bytes ? state_words * 4 : rows_bytes;
+    } else {
+        bytes = (state_words + (size_t)EPW * A * 3 * W + 1 + (size_t)(A > 0 ? A : 1)) * 4;
+    }
+    return (bytes + 15) & ~(size_t)15;
 }
 
 hipError_t launch_pack_obstacles(const uint8_t* obstacles, uint32_t* bm, int batch, int H, int Wd, int r,

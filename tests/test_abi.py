@@ -1,0 +1,91 @@
+"""CPU: the C-ABI library loads and exports every symbol include/pogema_amd.h declares; argument
+validation and error reporting work without a GPU (no compute call is made)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from pogema_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "pogema_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pgx_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_exported(engine_lib):
+    names = declared_symbols()
+    assert len(names) >= 12
+    for name in names:
+        assert hasattr(engine_lib, name), f"{name} declared in include/pogema_amd.h but not exported"
+    assert set(names) == set(_lib.EXPORTED_SYMBOLS)
+
+
+def test_abi_version(engine_lib):
+    assert engine_lib.pgx_abi_version() == _lib.PGX_ABI_VERSION
+
+
+def test_config_struct_layout():
+    # must match `struct pgx_config` in the header: 10 x int32, uint64, int64
+    assert C.sizeof(_lib.PgxConfig) == 10 * 4 + 8 + 8
+    assert _lib.PgxConfig.seed.offset == 40 and _lib.PgxConfig.env_index_base.offset == 48
+
+
+@pytest.mark.parametrize("field,value,needle", [
+    ("batch", 0, "batch"), ("num_agents", 0, "num_agents"), ("num_agents", 5000, "num_agents"),
+    ("obs_radius", 0, "obs_radius"), ("obs_radius", 16, "obs_radius"), ("collision_system", 7, "collision"),
+    ("on_target", -1, "on_target"), ("height", 0, "map size"), ("width", 4096, "map size"),
+])
+def test_create_rejects_bad_config(engine_lib, field, value, needle):
+    cfg = _lib.PgxConfig(batch=4, height=8, width=8, num_agents=2, obs_radius=3, collision_system=0, on_target=0,
+                         max_episode_steps=64, auto_reset=0, reserved0=0, seed=0, env_index_base=0)
+    setattr(cfg, field, value)
+    handle = C.c_void_p()
+    status = engine_lib.pgx_create(C.byref(cfg), 0, C.byref(handle))
+    assert status == -1 and not handle.value
+    assert needle in engine_lib.pgx_last_error().decode()
+
+
+def test_lds_limit_is_reported(engine_lib):
+    cfg = _lib.PgxConfig(batch=1, height=1024, width=1024, num_agents=64, obs_radius=15, collision_system=0,
+                         on_target=0, max_episode_steps=64, auto_reset=0, reserved0=0, seed=0, env_index_base=0)
+    handle = C.c_void_p()
+    assert engine_lib.pgx_create(C.byref(cfg), 0, C.byref(handle)) == -1
+    assert "LDS" in engine_lib.pgx_last_error().decode()
+
+
+def test_null_arguments(engine_lib):
+    assert engine_lib.pgx_step(None, None, 0, None, None, None, None, None, None) == -1
+    assert engine_lib.pgx_observe(None, None, None) == -1
+    assert engine_lib.pgx_destroy(None) == 0
+
+
+def test_no_device_fails_loudly_not_silently(engine_lib):
+    """Without a GPU the product must raise, never fall back to a CPU path."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from pogema_amd import GridConfig, VecPogema
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        VecPogema(GridConfig(num_agents=2), batch=2)
+    cfg = _lib.PgxConfig(batch=4, height=8, width=8, num_agents=2, obs_radius=3, collision_system=0, on_target=0,
+                         max_episode_steps=64, auto_reset=0, reserved0=0, seed=0, env_index_base=0)
+    handle = C.c_void_p()
+    assert engine_lib.pgx_create(C.byref(cfg), 0, C.byref(handle)) == -2  # PGX_E_HIP
+    assert not handle.value
+
+
+def test_product_never_imports_oracle():
+    """oracle/ is test infrastructure: nothing under pogema_amd/ may import, load or link it."""
+    pkg = os.path.join(ROOT, "pogema_amd")
+    banned = ("import oracle", "from oracle", "libpogema_oracle", "pogema_oracle", "c_oracle")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                for word in banned:
+                    assert word not in text, f"{f} references {word!r}"

@@ -1,0 +1,125 @@
+"""GPU, BASELINE.json full sizes: (1) bit-exact parity with the plain-C oracle port for a few steps at
+the full batch of configs[2], configs[3] (one GPU's shard) and configs[4]; (2) size-independent
+invariants over longer rollouts (no oracle needed): cell exclusivity, nobody on an obstacle,
+observation-plane identities, determinism, auto-reset returns to the stored initial state."""
+import numpy as np
+import pytest
+import torch
+
+from util import generate_instances
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(B, size, A, r, collision, on_target, max_steps, auto_reset, obstacles, agents, targets, seed=0):
+    from pogema_amd import GridConfig, VecPogema
+    gc = GridConfig(size=size, num_agents=A, obs_radius=r, collision_system=collision, on_target=on_target,
+                    max_episode_steps=max_steps, seed=seed, density=0.3)
+    env = VecPogema(gc, batch=B, auto_reset=auto_reset)
+    obs0 = env.reset_from_state(obstacles, agents, targets, validate=False)
+    return env, obs0
+
+
+FULL = [
+    # name, batch, size, agents, r, steps, compare_obs_every_step
+    ("configs2", 8192, 64, 64, 5, 3),
+    ("configs3_shard", 8192, 32, 16, 5, 4),
+    ("configs4", 4096, 256, 256, 7, 2),
+]
+
+
+@pytest.mark.parametrize("cfg", FULL, ids=[c[0] for c in FULL])
+@pytest.mark.parametrize("collision", ["soft", "priority", "block_both"])
+def test_full_size_parity_with_c_oracle(cfg, collision):
+    from oracle.c_oracle import COracle
+    name, B, size, A, r, T = cfg
+    obstacles, agents, targets = generate_instances(B, size, size, A, 0.3, 7)
+    rng = np.random.default_rng(3)
+    actions = rng.integers(0, 5, size=(T, B, A)).astype(np.int64)
+    ref = COracle(B, size, size, A, r, collision, "finish", 2, True)  # max_episode_steps=2: auto-reset is exercised
+    ref_obs0 = ref.reset(obstacles, agents, targets)
+    env, obs0 = _engine(B, size, A, r, collision, "finish", 2, True, obstacles, agents, targets)
+    check_obs = collision == "soft"  # the observation path is identical for all systems; compare it once
+    if check_obs:
+        assert np.array_equal(obs0.cpu().numpy(), ref_obs0)
+    del ref_obs0, obs0
+    threads = min(32, len(__import__("os").sched_getaffinity(0)))
+    for t in range(T):
+        robs, rrew, rterm, rtrunc, ract = ref.step(actions[t], nthreads=threads, compute_obs=check_obs)
+        obs, rew, term, trunc, info = env.step(torch.from_numpy(actions[t]).cuda(), compute_obs=check_obs)
+        st, rst = env.get_state(), ref.get_state()
+        assert np.array_equal(st["agents_xy"].cpu().numpy(), rst["agents_xy"]), f"{name} step {t}: positions"
+        assert np.array_equal(st["targets_xy"].cpu().numpy(), rst["targets_xy"])
+        assert np.array_equal(st["is_active"].cpu().numpy(), rst["is_active"])
+        assert np.array_equal(st["elapsed"].cpu().numpy(), rst["elapsed"])
+        assert np.array_equal(term.cpu().numpy(), rterm) and np.array_equal(trunc.cpu().numpy(), rtrunc)
+        assert np.array_equal(info["is_active"].cpu().numpy(), ract)
+        np.testing.assert_allclose(rew.cpu().numpy(), rrew, rtol=0, atol=1e-6)
+        if check_obs:
+            assert np.array_equal(obs.cpu().numpy(), robs), f"{name} step {t}: observations"
+            del obs, robs
+    env.close()
+    ref.close()
+
+
+@pytest.mark.parametrize("collision", ["priority", "block_both", "soft"])
+@pytest.mark.parametrize("on_target", ["finish", "restart", "nothing"])
+def test_invariants_configs2(collision, on_target):
+    B, size, A, r, T = 8192, 64, 64, 5, 40
+    obstacles, agents, targets = generate_instances(B, size, size, A, 0.3, 11)
+    env, obs = _engine(B, size, A, r, collision, on_target, 16, True, obstacles, agents, targets, seed=5)
+    d_obst = torch.from_numpy(obstacles).cuda()
+    bi = torch.arange(B, device="cuda")[:, None]
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    W = 2 * r + 1
+    for t in range(T):
+        acts = torch.randint(0, 5, (B, A), generator=gen, device="cuda")
+        obs, rew, term, trunc, info = env.step(acts)
+        st = env.get_state(occupancy=True)
+        xy, active = st["agents_xy"].long(), st["is_active"]
+        # nobody stands on an obstacle or outside the map
+        assert (xy >= 0).all() and (xy < size).all()
+        assert (d_obst[bi, xy[..., 0], xy[..., 1]] == 0).all()
+        # visible agents occupy pairwise distinct cells; occupancy array == scatter of visible agents
+        key = xy[..., 0] * size + xy[..., 1]
+        key = torch.where(active, key, -1 - torch.arange(A, device="cuda")[None, :])
+        srt = key.sort(dim=1).values
+        assert (srt[:, 1:] != srt[:, :-1]).all()
+        assert int(st["occupancy"].sum()) == int(active.sum())
+        # observation identities: target plane has exactly one 1; a visible agent sees itself at the centre
+        # (a hidden, finished agent may see another agent passing over its cell)
+        assert torch.equal(obs[:, :, 2].sum(dim=(2, 3)), torch.ones(B, A, device="cuda"))
+        assert (obs[:, :, 1, r, r][active] == 1).all()
+        assert (obs[:, :, 0, r, r] == 0).all()  # never inside an obstacle
+        assert ((obs == 0) | (obs == 1)).all()
+        # rewards are 0/1, truncation is all-or-none per env
+        assert ((rew == 0) | (rew == 1)).all()
+        assert (trunc.all(dim=1) | (~trunc).all(dim=1)).all()
+        if on_target == "restart":
+            assert not term.any()
+        if on_target == "nothing":
+            assert (term.all(dim=1) | (~term).all(dim=1)).all()
+        el = st["elapsed"]
+        assert (el >= 0).all() and (el < 16).all()  # auto-reset at the time limit
+    env.close()
+
+
+def test_determinism_and_reset_restores_initial_state():
+    B, size, A, r = 2048, 32, 16, 5
+    obstacles, agents, targets = generate_instances(B, size, size, A, 0.3, 2)
+    outs = []
+    for rep in range(2):
+        env, obs0 = _engine(B, size, A, r, "soft", "finish", 8, True, obstacles, agents, targets)
+        gen = torch.Generator(device="cuda").manual_seed(4)
+        trace = [obs0.clone()]
+        for t in range(8):  # the 8th step truncates every env -> all reset to the initial state
+            obs, *_ = env.step(torch.randint(0, 5, (B, A), generator=gen, device="cuda"))
+            trace.append(obs.clone())
+        st = env.get_state()
+        assert np.array_equal(st["agents_xy"].cpu().numpy(), agents)
+        assert np.array_equal(st["targets_xy"].cpu().numpy(), targets)
+        assert st["is_active"].all() and (st["elapsed"] == 0).all()
+        assert torch.equal(trace[-1], trace[0]), "observation after auto-reset == first observation"
+        outs.append(torch.stack(trace))
+        env.close()
+    assert torch.equal(outs[0], outs[1])

@@ -1,0 +1,58 @@
+"""CPU: GridConfig mirrors the reference's fields, defaults and validation."""
+import pytest
+from pydantic import ValidationError
+
+from pogema_amd import GridConfig
+from pogema_amd.grid_config import MOVES, str_map_to_list
+
+
+def test_defaults():
+    gc = GridConfig()
+    assert (gc.on_target, gc.seed, gc.size, gc.density, gc.num_agents, gc.obs_radius) == ("finish", None, 8, 0.3, 1, 5)
+    assert gc.collision_system == "priority" and gc.observation_type == "default" and gc.max_episode_steps == 64
+    assert gc.persistent is False and gc.map is None and gc.empty_outside is True
+    assert gc.FREE == 0 and gc.OBSTACLE == 1
+    assert gc.MOVES == [[0, 0], [-1, 0], [1, 0], [0, -1], [0, 1]] == MOVES
+
+
+@pytest.mark.parametrize("kw", [dict(size=1), dict(size=1025), dict(density=-0.1), dict(density=1.5), dict(num_agents=0),
+                                dict(obs_radius=0), dict(obs_radius=129), dict(seed=-1), dict(on_target="bogus"),
+                                dict(collision_system="hard"), dict(observation_type="x")])
+def test_validation_ranges(kw):
+    with pytest.raises(ValidationError):
+        GridConfig(**kw)
+
+
+def test_string_map():
+    gc = GridConfig(map="""
+        a.#.
+        .#.A
+        b..B
+    """)
+    assert gc.map == [[0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 0]]
+    assert gc.num_agents == 2 and gc.agents_xy == [[0, 0], [2, 0]] and gc.targets_xy == [[1, 3], [2, 3]]
+    assert gc.size == 4 and gc.map_shape == (3, 4)
+    assert abs(gc.density - 2 / 12) < 1e-12
+
+
+def test_map_errors():
+    with pytest.raises(Exception):
+        GridConfig(map="a.\n..")  # agent without target
+    with pytest.raises(Exception):
+        GridConfig(map="..\n...")  # ragged
+    with pytest.raises(Exception):
+        GridConfig(map="..\n.?")
+    with pytest.raises(Exception):
+        GridConfig(map=[[0, 0], [0, 0]], agents_xy=[[0, 0]], targets_xy=[[5, 5]])
+    with pytest.raises(Exception):
+        GridConfig(map=[[0, 0], [0, 0]], agents_xy=[[0, 0]])
+
+
+def test_explicit_positions_set_num_agents():
+    gc = GridConfig(map=[[0, 0, 0], [0, 1, 0]], agents_xy=[[0, 0], [1, 0]], targets_xy=[[0, 2], [1, 2]])
+    assert gc.num_agents == 2 and gc.map_shape == (2, 3)
+
+
+def test_str_map_to_list_roundtrip():
+    rows, a, t = str_map_to_list("#.\n.#")
+    assert rows == [[1, 0], [0, 1]] and a == [] and t == []

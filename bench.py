@@ -79,7 +79,7 @@ def cpu_baseline(size, agents, r, collision, density, max_steps, target_seconds=
         env.step(pool[steps % 16], nthreads=cores, out=out)
         steps += 1
         dt = time.perf_counter() - t0
-        if dt >= target_seconds or steps >= 4000:
+        if dt >= target_seconds or steps >= 200000:
             break
     env.close()
     return {"value": B * agents * steps / dt, "unit": "agent-steps/s", "cores": cores, "kind": "port",

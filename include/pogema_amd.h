@@ -119,6 +119,16 @@ int pgx_reset_from_state(pgx_env* env, const uint8_t* obstacles, const int32_t* 
 int pgx_step(pgx_env* env, const void* actions, int action_dtype, float* obs, float* rewards,
              uint8_t* terminated, uint8_t* truncated, uint8_t* is_active, void* stream);
 
+/* Episode metrics, fused into pgx_step.  Replaces the metric wrappers of upstream pogema/wrappers/metrics.py
+ * (ISR / CSR / ep_length / SoC / makespan, their non-disappearing forms for on_target = NOTHING, and
+ * avg_throughput for lifelong), which put `infos[0]['metrics']` on the step that ends an episode.
+ * Registers caller-owned device buffers written by every following pgx_step (NULL disables either):
+ *   metrics       f32 [batch, 6]  ISR, CSR, ep_length, SoC, makespan, avg_throughput -- a row is written only
+ *                                 on the step in which that env's episode finishes
+ *   episode_done  u8  [batch]     1 iff all agents of the env are terminated or truncated in this step */
+#define PGX_NUM_METRICS 6
+int pgx_set_metrics_buffers(pgx_env* env, float* metrics, uint8_t* episode_done);
+
 /* Observation of the current state without stepping.  Replaces `PogemaBase._obs()` as called by
  * `reset()`. */
 int pgx_observe(pgx_env* env, float* obs, void* stream);

@@ -39,7 +39,7 @@ def load(build_if_missing: bool = True):
     lib.po_create.restype = vp
     lib.po_destroy.argtypes = [vp]
     lib.po_reset.argtypes = [vp, vp, vp, vp]
-    lib.po_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int]
+    lib.po_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int]
     lib.po_observe.argtypes = [vp, vp]
     lib.po_get_state.argtypes = [vp, vp, vp, vp, vp, vp]
     _lib = lib
@@ -89,8 +89,11 @@ class COracle:
                    np.empty((self.B, self.A), np.float32), np.empty((self.B, self.A), np.uint8),
                    np.empty((self.B, self.A), np.uint8), np.empty((self.B, self.A), np.uint8))
         obs, rew, term, trunc, act = out
+        self.metrics = np.zeros((self.B, 6), np.float32)
+        self.episode_done = np.zeros((self.B,), np.uint8)
         self.lib.po_step(self.h, acts.ctypes.data, obs.ctypes.data if obs is not None else None, rew.ctypes.data,
-                         term.ctypes.data, trunc.ctypes.data, act.ctypes.data, int(nthreads))
+                         term.ctypes.data, trunc.ctypes.data, act.ctypes.data, self.metrics.ctypes.data,
+                         self.episode_done.ctypes.data, int(nthreads))
         return obs, rew, term.astype(bool), trunc.astype(bool), act.astype(bool)
 
     def get_state(self, occupancy=False):

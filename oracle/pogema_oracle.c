@@ -49,6 +49,7 @@ typedef struct po_env {
     int32_t* elapsed; /* [B] */
     /* lifelong */
     uint32_t* tcount;      /* [B][A] */
+    int32_t* macc;         /* [B][4] metric accumulators: solved, sum of solve steps, max solve step, lifelong goals */
     int32_t* comp_begin;   /* [B][H*W] */
     int32_t* comp_len;     /* [B][H*W] */
     int32_t* comp_cells;   /* [B][H*W] unpadded cell index, grouped by component, row-major inside */
@@ -89,6 +90,7 @@ po_env* po_create(const po_config* cfg) {
     e->active = (uint8_t*)calloc(B * A, 1);
     e->elapsed = (int32_t*)calloc(B, sizeof(int32_t));
     e->tcount = (uint32_t*)calloc(B * A, sizeof(uint32_t));
+    e->macc = (int32_t*)calloc(B * 4, sizeof(int32_t));
     if (cfg->on_target == 1) {
         e->comp_begin = (int32_t*)calloc(B * cells, sizeof(int32_t));
         e->comp_len = (int32_t*)calloc(B * cells, sizeof(int32_t));
@@ -101,7 +103,7 @@ void po_destroy(po_env* e) {
     if (!e) return;
     free(e->obst); free(e->occ); free(e->px); free(e->py); free(e->fx); free(e->fy);
     free(e->px0); free(e->py0); free(e->fx0); free(e->fy0); free(e->active); free(e->elapsed);
-    free(e->tcount); free(e->comp_begin); free(e->comp_len); free(e->comp_cells);
+    free(e->tcount); free(e->macc); free(e->comp_begin); free(e->comp_len); free(e->comp_cells);
     free(e);
 }
 
@@ -158,6 +160,7 @@ static void install_initial(po_env* e, int b) {
         occ[(size_t)e->px[g] * e->PW + e->py[g]] = 1;
     }
     e->elapsed[b] = 0;
+    memset(e->macc + (size_t)b * 4, 0, 4 * sizeof(int32_t));
 }
 
 /* Grid.__init__ + add_artificial_border */
@@ -371,14 +374,48 @@ static void write_obs(const po_env* e, int b, float* obs) {
     }
 }
 
+/* metric wrappers (upstream pogema/wrappers/metrics.py, recollection -- DESIGN.md open question 9).
+ * out[6] = ISR, CSR, ep_length, SoC, makespan, avg_throughput; written only when the episode finished. */
+static void compute_metrics(po_env* e, int b, int step, int n_arrived, int n_on_goal, int finished, float* out) {
+    int32_t* m = e->macc + (size_t)b * 4;
+    const int A = e->c.num_agents;
+    if (e->c.on_target == 0) {
+        m[0] += n_arrived;
+        m[1] += n_arrived * step;
+        if (n_arrived) m[2] = step > m[2] ? step : m[2];
+    } else if (e->c.on_target == 1) {
+        m[3] += n_arrived;
+    }
+    if (!finished || !out) return;
+    if (e->c.on_target == 0) {
+        const int unsolved = A - m[0];
+        const int total = m[1] + unsolved * step;
+        const int mx = unsolved ? step : m[2];
+        out[0] = (float)m[0] / (float)A; out[1] = m[0] == A ? 1.0f : 0.0f; out[2] = (float)total / (float)A + 1.0f;
+        out[3] = (float)(total + A); out[4] = (float)(mx + 1); out[5] = 0.0f;
+    } else if (e->c.on_target == 2) {
+        out[0] = (float)n_on_goal / (float)A; out[1] = n_on_goal == A ? 1.0f : 0.0f; out[2] = (float)(step + 1);
+        out[3] = (float)(A * (step + 1)); out[4] = (float)(step + 1); out[5] = 0.0f;
+    } else {
+        const int denom = e->c.max_episode_steps > 0 ? e->c.max_episode_steps : step + 1;
+        out[0] = 0.0f; out[1] = 0.0f; out[2] = (float)(step + 1); out[3] = 0.0f; out[4] = 0.0f;
+        out[5] = (float)m[3] / (float)denom;
+    }
+}
+
 static void step_env(po_env* e, int b, const int64_t* actions, float* obs, float* rewards, uint8_t* terminated,
-                     uint8_t* truncated, uint8_t* active_out, scratch* s) {
+                     uint8_t* truncated, uint8_t* active_out, float* metrics, uint8_t* episode_done, scratch* s) {
     const int A = e->c.num_agents, r = e->c.obs_radius;
     const size_t base = (size_t)b * A;
     const size_t P = (size_t)e->PH * e->PW;
     uint8_t* occ = e->occ + (size_t)b * P;
     move_agents(e, b, actions + base, s);
     int all_term = 1;
+    int n_arrived = 0;  /* was_on_goal: on goal and still active right after the moves */
+    for (int i = 0; i < A; ++i) {
+        const size_t g = base + i;
+        n_arrived += e->active[g] && e->px[g] == e->fx[g] && e->py[g] == e->fy[g];
+    }
     if (e->c.on_target == 0) {
         for (int i = 0; i < A; ++i) {
             const size_t g = base + i;
@@ -425,13 +462,17 @@ static void step_env(po_env* e, int b, const int64_t* actions, float* obs, float
     e->elapsed[b] += 1;
     const int trunc = e->c.max_episode_steps > 0 && e->elapsed[b] >= e->c.max_episode_steps;
     for (int i = 0; i < A; ++i) truncated[base + i] = (uint8_t)trunc;
-    if (e->c.auto_reset && (all_term || trunc)) install_initial(e, b);
+    const int finished = all_term || trunc;
+    compute_metrics(e, b, e->elapsed[b] - 1, n_arrived, n_arrived, finished, metrics ? metrics + (size_t)b * 6 : NULL);
+    if (episode_done) episode_done[b] = (uint8_t)finished;
+    if (finished) memset(e->macc + (size_t)b * 4, 0, 4 * sizeof(int32_t));
+    if (e->c.auto_reset && finished) install_initial(e, b);
     if (obs) write_obs(e, b, obs);
 }
 
 /* One step for the whole batch; nthreads > 1 uses OpenMP over environments. */
 int po_step(po_env* e, const int64_t* actions, float* obs, float* rewards, uint8_t* terminated, uint8_t* truncated,
-            uint8_t* active_out, int nthreads) {
+            uint8_t* active_out, float* metrics, uint8_t* episode_done, int nthreads) {
     const int B = e->c.batch;
     const size_t P = (size_t)e->PH * e->PW;
     if (nthreads < 1) nthreads = 1;
@@ -439,7 +480,7 @@ int po_step(po_env* e, const int64_t* actions, float* obs, float* rewards, uint8
     {
         scratch* s = scratch_new(P, e->c.num_agents);
 #pragma omp for schedule(static)
-        for (int b = 0; b < B; ++b) step_env(e, b, actions, obs, rewards, terminated, truncated, active_out, s);
+        for (int b = 0; b < B; ++b) step_env(e, b, actions, obs, rewards, terminated, truncated, active_out, metrics, episode_done, s);
         scratch_free(s);
     }
     return 0;

@@ -195,7 +195,16 @@ class PogemaOracle:
         self.reset()
 
     # ------------------------------------------------------------------------------------------
+    def _reset_metrics(self):
+        # accumulators of the metrics wrappers (upstream `pogema/wrappers/metrics.py`):
+        # number of agents that reached their goal, sum and max of their solve steps, goals in lifelong mode
+        self._m_solved = 0
+        self._m_sum = 0
+        self._m_max = 0
+        self._m_goals = 0
+
     def reset(self):
+        self._reset_metrics()
         obstacles, agents_xy, targets_xy = self._init_args
         self.grid = Grid(obstacles, agents_xy, targets_xy, self.obs_radius)
         self._elapsed_steps = 0
@@ -293,6 +302,8 @@ class PogemaOracle:
         g = self.grid
         n = self.num_agents
         self.move_agents(actions)
+        # `was_on_goal` of the reference: on goal and still active right after the moves
+        was_on_goal = [bool(g.on_goal(i) and g.is_active[i]) for i in range(n)]
         if self.on_target == "finish":
             rewards, terminated = [], []
             for i in range(n):
@@ -321,10 +332,63 @@ class PogemaOracle:
         self._elapsed_steps += 1
         if self._elapsed_steps >= self.max_episode_steps:
             truncated = [True] * n
+        finished = all(terminated) or all(truncated)
+        metrics = self._compute_metrics(self._elapsed_steps - 1, was_on_goal, finished)
+        if metrics is not None:
+            infos[0]["metrics"] = metrics
         obs = self._obs()
-        if self.auto_reset and (all(terminated) or all(truncated)):
+        if self.auto_reset and finished:
             obs = self.reset()
+        elif finished:
+            self._reset_metrics()
         return obs, rewards, terminated, truncated, infos
+
+    def _compute_metrics(self, step, was_on_goal, finished):
+        """Metric wrappers restated (recollection of upstream `pogema/wrappers/metrics.py`, conf. med --
+        DESIGN.md open question 9): ISR / CSR / ep_length / SoC / makespan for disappearing agents,
+        their 'NonDisappear' forms for on_target='nothing', avg_throughput for lifelong."""
+        n = self.num_agents
+        if self.on_target == "finish":
+            for hit in was_on_goal:
+                if hit:
+                    self._m_solved += 1
+                    self._m_sum += step
+                    self._m_max = max(self._m_max, step)
+        elif self.on_target == "restart":
+            self._m_goals += sum(was_on_goal)
+        if not finished:
+            return None
+        if self.on_target == "finish":
+            unsolved = n - self._m_solved
+            total = self._m_sum + unsolved * step
+            mx = step if unsolved else self._m_max
+            return {"ISR": self._m_solved / n, "CSR": float(self._m_solved == n), "ep_length": total / n + 1,
+                    "SoC": float(total + n), "makespan": float(mx + 1), "avg_throughput": 0.0}
+        if self.on_target == "nothing":
+            on = sum(was_on_goal)
+            return {"ISR": on / n, "CSR": float(on == n), "ep_length": float(step + 1), "SoC": float(n * (step + 1)),
+                    "makespan": float(step + 1), "avg_throughput": 0.0}
+        denom = self.max_episode_steps if self.max_episode_steps > 0 else step + 1
+        return {"ISR": 0.0, "CSR": 0.0, "ep_length": float(step + 1), "SoC": 0.0, "makespan": 0.0,
+                "avg_throughput": self._m_goals / denom}
+
+    # -- POMAPF / MAPF dict observations (upstream `PogemaBase._pomapf_obs` / `_mapf_obs`) ----------
+    def pomapf_obs(self, global_info=False):
+        g = self.grid
+        r = self.obs_radius
+        starts = [(x + r, y + r) for x, y in self._init_args[1]]
+        out = []
+        for i in range(self.num_agents):
+            x0, y0 = starts[i]
+            d = {"obstacles": g.get_obstacles_for_agent(i), "agents": g.get_positions(i),
+                 "xy": (g.positions_xy[i][0] - x0, g.positions_xy[i][1] - y0),
+                 "target_xy": (g.finishes_xy[i][0] - x0, g.finishes_xy[i][1] - y0)}
+            if global_info:
+                d["global_obstacles"] = g.obstacles[r:-r, r:-r].astype(np.float32)
+                d["global_xy"] = (g.positions_xy[i][0] - r, g.positions_xy[i][1] - r)
+                d["global_target_xy"] = (g.finishes_xy[i][0] - r, g.finishes_xy[i][1] - r)
+            out.append(d)
+        return out
 
     def _generate_new_target(self, agent_idx):
         r = self.obs_radius

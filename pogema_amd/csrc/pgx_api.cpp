@@ -77,6 +77,9 @@ struct pgx_env {
     uint32_t *pos = nullptr, *tgt = nullptr, *pos0 = nullptr, *tgt0 = nullptr;
     uint8_t* active = nullptr;
     int32_t* elapsed = nullptr;
+    int4* macc = nullptr;
+    float* metrics_out = nullptr;   // caller-owned (pgx_set_metrics_buffers)
+    uint8_t* episode_done = nullptr; // caller-owned
     unsigned long long* dbg = nullptr;
     size_t dbg_elems = 0;
     uint32_t *comp_begin = nullptr, *comp_len = nullptr, *comp_cells = nullptr, *tcount = nullptr;
@@ -152,6 +155,7 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
     alloc((void**)&e->tgt0, BA * sizeof(uint32_t));
     alloc((void**)&e->active, BA);
     alloc((void**)&e->elapsed, B * sizeof(int32_t));
+    alloc((void**)&e->macc, B * sizeof(int4));
     if (cfg->on_target == PGX_ON_TARGET_RESTART) {
         const size_t cells = B * (size_t)cfg->height * cfg->width;
         alloc((void**)&e->comp_begin, cells * sizeof(uint32_t));
@@ -178,7 +182,7 @@ int pgx_destroy(pgx_env* e) {
     if (!e) return PGX_OK;
     DeviceGuard guard(e->device);
     void* ptrs[] = {e->obst,   e->pos,     e->tgt,        e->pos0,     e->tgt0,       e->active,
-                    e->elapsed, e->comp_begin, e->comp_len, e->comp_cells, e->tcount, e->dbg};
+                    e->elapsed, e->comp_begin, e->comp_len, e->comp_cells, e->tcount, e->dbg, e->macc};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete e;
@@ -253,6 +257,7 @@ int pgx_reset_from_state(pgx_env* e, const uint8_t* obstacles, const int32_t* ag
     PGX_HIP(pgx::launch_pack_agents(agent_xy, target_xy, e->pos, e->tgt, e->pos0, e->tgt0, e->active, e->tcount, BA,
                                     c.obs_radius, s));
     PGX_HIP(pgx::launch_zero_i32(e->elapsed, B, s));
+    PGX_HIP(pgx::launch_zero_i32(reinterpret_cast<int32_t*>(e->macc), B * 4, s));
     if (c.on_target == PGX_ON_TARGET_RESTART) {
         const size_t cells = (size_t)c.height * c.width;
         std::vector<uint8_t> h_obst(B * cells);
@@ -310,6 +315,9 @@ static void fill_params(const pgx_env* e, pgx::StepParams& p) {
     p.comp_cells = e->comp_cells;
     p.tcount = e->tcount;
     p.dbg = e->dbg;
+    p.macc = e->macc;
+    p.metrics_out = e->metrics_out;
+    p.episode_done = e->episode_done;
 }
 
 int pgx_step(pgx_env* e, const void* actions, int action_dtype, float* obs, float* rewards, uint8_t* terminated,
@@ -330,6 +338,13 @@ int pgx_step(pgx_env* e, const void* actions, int action_dtype, float* obs, floa
     p.truncated = truncated;
     p.act_out = is_active;
     PGX_HIP(pgx::launch_step(p, e->K, e->G, e->p16, e->lds_bytes, (hipStream_t)stream));
+    return PGX_OK;
+}
+
+int pgx_set_metrics_buffers(pgx_env* e, float* metrics, uint8_t* episode_done) {
+    if (!e) return fail(PGX_E_INVALID, "pgx_set_metrics_buffers: null handle");
+    e->metrics_out = metrics;
+    e->episode_done = episode_done;
     return PGX_OK;
 }
 

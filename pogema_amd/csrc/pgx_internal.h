@@ -37,6 +37,10 @@ struct StepParams {
     const uint32_t* comp_len;    // [B][H*W]  size of the cell's component
     const uint32_t* comp_cells;  // [B][H*W]  unpadded packed cells grouped by component, row-major inside
     uint32_t* tcount;            // [B][A]    targets drawn so far
+    // metric accumulators (pogema/wrappers/metrics.py): {agents solved, sum of solve steps, max solve step, lifelong goals}
+    int4* macc;                  // [B]
+    float* metrics_out;          // [B][6] ISR, CSR, ep_length, SoC, makespan, avg_throughput (caller-owned, may be null)
+    uint8_t* episode_done;       // [B]    1 when the env's episode finished in this step            (may be null)
     // I/O (caller-owned device buffers)
     const void* actions;
     float* obs;

@@ -241,6 +241,9 @@ __global__ __launch_bounds__((K == 1) ? 64 : 256) void step_kernel(const StepPar
         }
         if (env_ok && p.mode == MODE_STEP) elapsed = p.elapsed[env];
     }
+    int4 macc = make_int4(0, 0, 0, 0);
+    const bool env_leader = resolver && env_ok && alane == 0 && p.mode == MODE_STEP;
+    if (env_leader) macc = p.macc[env];
 
     // ---- phase 1: stage obstacle bitmaps HBM -> LDS, clear the occupancy bitmaps ---------------
     {
@@ -355,10 +358,14 @@ __global__ __launch_bounds__((K == 1) ? 64 : 256) void step_kernel(const StepPar
             bool all_goal_l = true, all_term_l = true;
             float rew[K];
             uint8_t term[K];
+            int n_arrived = 0;  // `was_on_goal` of the reference: on goal and still active right after the moves
 #pragma unroll
             for (int s = 0; s < K; ++s) {
                 on_goal[s] = valid[s] && pos[s] == tgt[s];
                 if (valid[s]) all_goal_l = all_goal_l && on_goal[s] && active[s];
+                const unsigned long long m = __ballot(on_goal[s] && active[s]);
+                if constexpr (G == 64) n_arrived += __popcll(m);
+                else n_arrived += __popcll((m >> gbase) & ((1ull << G) - 1ull));
             }
             // env-wide AND (all lanes of the group; invalid lanes contribute true)
             const bool solved = !group_any<G>(!all_goal_l, gbase);
@@ -418,7 +425,39 @@ __global__ __launch_bounds__((K == 1) ? 64 : 256) void step_kernel(const StepPar
                     p.active[gi] = active[s] ? 1 : 0;
                 }
             }
-            if (env_ok && alane == 0) p.elapsed[env] = do_reset ? 0 : elapsed;
+            if (env_leader) {
+                p.elapsed[env] = do_reset ? 0 : elapsed;
+                // ---- metric wrappers, fused: per-env accumulators, emitted when the episode finishes ----
+                const bool finished = all_term || trunc;
+                const int step = elapsed - 1;
+                if (p.on_target == ON_TARGET_FINISH) {
+                    macc.x += n_arrived;
+                    macc.y += n_arrived * step;
+                    if (n_arrived) macc.z = max(macc.z, step);
+                } else if (p.on_target == ON_TARGET_RESTART) {
+                    macc.w += n_arrived;
+                }
+                if (finished && p.metrics_out) {
+                    float* mo = p.metrics_out + (size_t)env * 6;
+                    const float fA = (float)A;
+                    if (p.on_target == ON_TARGET_FINISH) {
+                        const int unsolved = A - macc.x;
+                        const int total = macc.y + unsolved * step;
+                        const int mx = unsolved ? step : macc.z;
+                        mo[0] = (float)macc.x / fA; mo[1] = macc.x == A ? 1.0f : 0.0f; mo[2] = (float)total / fA + 1.0f;
+                        mo[3] = (float)(total + A); mo[4] = (float)(mx + 1); mo[5] = 0.0f;
+                    } else if (p.on_target == ON_TARGET_NOTHING) {
+                        mo[0] = (float)n_arrived / fA; mo[1] = n_arrived == A ? 1.0f : 0.0f; mo[2] = (float)(step + 1);
+                        mo[3] = (float)(A * (step + 1)); mo[4] = (float)(step + 1); mo[5] = 0.0f;
+                    } else {
+                        const int denom = p.max_steps > 0 ? p.max_steps : step + 1;
+                        mo[0] = 0.0f; mo[1] = 0.0f; mo[2] = (float)(step + 1); mo[3] = 0.0f; mo[4] = 0.0f;
+                        mo[5] = (float)macc.w / (float)denom;
+                    }
+                }
+                if (p.episode_done) p.episode_done[env] = finished ? 1 : 0;
+                p.macc[env] = finished ? make_int4(0, 0, 0, 0) : macc;
+            }
         }
 
         // ---- publish agent cells to LDS and rebuild the occupancy bitmap ------------------------

@@ -57,8 +57,18 @@ class Pogema:
     def sample_actions(self):
         return [self.action_space.sample() for _ in range(self.get_num_agents())]
 
-    @staticmethod
-    def _obs_list(obs):
+    def _obs_list(self, obs):
+        if isinstance(obs, dict):  # POMAPF / MAPF: one dict per agent, as the reference returns
+            host = {k: v[0].cpu().numpy() for k, v in obs.items()}
+            n = self.get_num_agents()
+            per_agent = []
+            for i in range(n):
+                d = {k: (host[k] if k == "global_obstacles" else host[k][i]) for k in host}
+                for k in ("xy", "target_xy", "global_xy", "global_target_xy"):
+                    if k in d:
+                        d[k] = tuple(int(c) for c in d[k])
+                per_agent.append(d)
+            return per_agent
         host = obs[0].cpu().numpy()
         return [host[i] for i in range(host.shape[0])]
 
@@ -73,9 +83,19 @@ class Pogema:
     def step(self, action):
         assert len(action) == self.get_num_agents()
         obs, rewards, terminated, truncated, infos = self._vec.step(np.asarray(action, dtype=np.int64)[None])
+        info_list = [{"is_active": bool(v)} for v in infos["is_active"][0].cpu().numpy()]
+        if bool(infos["episode_done"][0]):  # metric wrappers: infos[0]['metrics'] on the step that ends the episode
+            from ._lib import METRIC_NAMES
+            values = infos["metrics"][0].cpu().numpy()
+            metrics = {k: float(v) for k, v in zip(METRIC_NAMES, values)}
+            if self.grid_config.on_target == "restart":
+                metrics = {"avg_throughput": metrics["avg_throughput"]}
+            else:
+                metrics.pop("avg_throughput")
+            info_list[0]["metrics"] = metrics
         return (self._obs_list(obs), [float(v) for v in rewards[0].cpu().numpy()],
                 [bool(v) for v in terminated[0].cpu().numpy()], [bool(v) for v in truncated[0].cpu().numpy()],
-                [{"is_active": bool(v)} for v in infos["is_active"][0].cpu().numpy()])
+                info_list)
 
     # ---- state accessors in the style of `Grid.get_agents_xy` etc. (unpadded coordinates) ----------
     def get_agents_xy(self):

@@ -31,15 +31,16 @@ class VecPogema:
     obs        float32 [batch, agents, 3, 2r+1, 2r+1]   (obstacles, agents, target)
     rewards    float32 [batch, agents]
     terminated / truncated   bool [batch, agents]
-    infos      {'is_active': bool [batch, agents]}
+    infos      {'is_active': bool [batch, agents], 'episode_done': bool [batch],
+                'metrics': float32 [batch, 6] (ISR, CSR, ep_length, SoC, makespan, avg_throughput; a row is
+                refreshed on the step where its env's episode ends -- mask with 'episode_done')}
     """
 
     def __init__(self, grid_config: Optional[GridConfig] = None, batch: int = 1, device="cuda:0",
                  env_index_base: int = 0, auto_reset: Optional[bool] = None, reuse_buffers: bool = False):
         self.grid_config = grid_config if grid_config is not None else GridConfig(num_agents=2)
         gc = self.grid_config
-        if gc.observation_type != "default":
-            raise NotImplementedError("only observation_type='default' is implemented by the engine")
+        self.observation_type = gc.observation_type  # 'default' tensor, or 'POMAPF' / 'MAPF' dict views
         if not gc.empty_outside:
             raise NotImplementedError("empty_outside=False draws from the reference's RNG; not implemented")
         if not torch.cuda.is_available():
@@ -70,6 +71,10 @@ class VecPogema:
         self._bufs = None
         self._buf_i = 0
         self._initial = None
+        # episode metrics (fused metric wrappers): rows are refreshed on the step that ends an env's episode
+        self.metrics = torch.zeros((self.batch, len(_lib.METRIC_NAMES)), dtype=torch.float32, device=self.device)
+        self.episode_done = torch.zeros((self.batch,), dtype=torch.bool, device=self.device)
+        _lib.check(self._lib.pgx_set_metrics_buffers(self._handle, self.metrics.data_ptr(), self.episode_done.data_ptr()))
 
     # ------------------------------------------------------------------------------------------
     def close(self):
@@ -171,8 +176,8 @@ class VecPogema:
         d_targets = torch.from_numpy(targets_xy).to(self.device)
         _lib.check(self._lib.pgx_reset_from_state(self._handle, d_obst.data_ptr(), d_agents.data_ptr(),
                                                   d_targets.data_ptr(), self._stream()))
-        self._initial = (d_obst, d_agents, d_targets)  # keep alive until the stream consumed them
-        return self.observe()
+        self._initial = (d_obst, d_agents, d_targets)  # initial state; xy of POMAPF/MAPF views is relative to it
+        return self._wrap_obs(self.observe())
 
     def reset(self, seed: Optional[int] = None, options=None):
         """gymnasium-style reset: draws fresh instances (env i uses seed + env_index_base + i) and
@@ -227,7 +232,24 @@ class VecPogema:
             self._handle, actions.data_ptr(), self._ACTION_CODE[actions.dtype],
             obs.data_ptr() if compute_obs else None, rewards.data_ptr(), terminated.data_ptr(),
             truncated.data_ptr(), is_active.data_ptr(), self._stream()))
-        return (obs if compute_obs else None), rewards, terminated, truncated, {"is_active": is_active}
+        infos = {"is_active": is_active, "episode_done": self.episode_done, "metrics": self.metrics}
+        return (self._wrap_obs(obs) if compute_obs else None), rewards, terminated, truncated, infos
+
+    def _wrap_obs(self, obs: torch.Tensor):
+        """'default': the float32 tensor.  'POMAPF' / 'MAPF' (upstream `PogemaBase._pomapf_obs` / `_mapf_obs`):
+        dict views over the same planes plus coordinates relative to each agent's start cell (and, for MAPF,
+        the global map and global coordinates).  No extra kernel besides the state export."""
+        if self.observation_type == "default":
+            return obs
+        st = self.get_state()
+        start = self._initial[1]
+        out = {"obstacles": obs[:, :, 0], "agents": obs[:, :, 1],
+               "xy": st["agents_xy"] - start, "target_xy": st["targets_xy"] - start}
+        if self.observation_type == "MAPF":
+            out["global_obstacles"] = self._initial[0].to(torch.float32)
+            out["global_xy"] = st["agents_xy"]
+            out["global_target_xy"] = st["targets_xy"]
+        return out
 
     # ------------------------------------------------------------------------------------------
     def get_state(self, occupancy: bool = False):

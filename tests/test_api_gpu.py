@@ -1,0 +1,105 @@
+"""GPU: the reference-style calling conventions on top of the engine -- `pogema_v0` list-per-agent
+API, metrics in infos[0], POMAPF / MAPF dict observations, PettingZoo-style dict view -- against
+the oracle driven with the same instance and actions."""
+import numpy as np
+import pytest
+
+from oracle.pogema_oracle import PogemaOracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_for(env, **kw):
+    obst, agents, targets = (t.cpu().numpy() for t in env._vec._initial)
+    gc = env.grid_config
+    return PogemaOracle(obst[0], agents[0], targets[0], obs_radius=gc.obs_radius, collision_system=gc.collision_system,
+                        on_target=gc.on_target, max_episode_steps=gc.max_episode_steps, seed=gc.seed or 0, **kw)
+
+
+@pytest.mark.parametrize("on_target", ["finish", "restart", "nothing"])
+def test_list_api_matches_oracle(on_target):
+    from pogema_amd import GridConfig, pogema_v0
+    gc = GridConfig(size=8, num_agents=2, obs_radius=3, density=0.3, seed=3, on_target=on_target, max_episode_steps=12,
+                    collision_system="soft")  # BASELINE.json configs[0]
+    env = pogema_v0(gc)
+    obs, infos = env.reset(seed=3)
+    ref = _oracle_for(env)
+    assert env.get_num_agents() == 2 and env.action_space.n == 5 and env.observation_space.shape == (3, 7, 7)
+    assert isinstance(obs, list) and len(obs) == 2 and obs[0].dtype == np.float32 and obs[0].shape == (3, 7, 7)
+    assert all(np.array_equal(a, b) for a, b in zip(obs, ref._obs()))
+    assert infos == [{"is_active": True}, {"is_active": True}]
+    rng = np.random.default_rng(0)
+    saw_metrics = False
+    for t in range(12):
+        acts = [int(a) for a in rng.integers(0, 5, size=2)]
+        obs, rew, term, trunc, infos = env.step(acts)
+        robs, rrew, rterm, rtrunc, rinfos = ref.step(acts)
+        assert all(np.array_equal(a, b) for a, b in zip(obs, robs))
+        assert rew == rrew and term == rterm and trunc == rtrunc
+        assert all(isinstance(v, float) for v in rew) and all(isinstance(v, bool) for v in term + trunc)
+        assert [i["is_active"] for i in infos] == [i["is_active"] for i in rinfos]
+        assert env.get_agents_xy() == [tuple(p) for p in ref.get_state()["agents_xy"].tolist()]
+        if "metrics" in rinfos[0]:
+            saw_metrics = True
+            want = rinfos[0]["metrics"]
+            keys = ["avg_throughput"] if on_target == "restart" else ["ISR", "CSR", "ep_length", "SoC", "makespan"]
+            assert set(infos[0]["metrics"]) == set(keys)
+            for k in keys:
+                assert abs(infos[0]["metrics"][k] - want[k]) < 1e-6, k
+        else:
+            assert "metrics" not in infos[0]
+    assert saw_metrics, "the time limit ends the episode within 12 steps"
+    env.close()
+
+
+@pytest.mark.parametrize("obs_type", ["POMAPF", "MAPF"])
+def test_dict_observations(obs_type):
+    from pogema_amd import GridConfig, pogema_v0
+    gc = GridConfig(size=10, num_agents=5, obs_radius=2, density=0.2, seed=1, observation_type=obs_type,
+                    collision_system="priority")
+    env = pogema_v0(gc)
+    obs, _ = env.reset(seed=1)
+    ref = _oracle_for(env)
+    rng = np.random.default_rng(2)
+    for t in range(10):
+        want = ref.pomapf_obs(global_info=(obs_type == "MAPF"))
+        assert len(obs) == 5
+        for got, exp in zip(obs, want):
+            assert set(got) == set(exp)
+            for k in exp:
+                if isinstance(exp[k], tuple):
+                    assert got[k] == tuple(int(v) for v in exp[k]), k
+                else:
+                    assert got[k].dtype == np.float32 and np.array_equal(got[k], exp[k]), k
+        acts = [int(a) for a in rng.integers(0, 5, size=5)]
+        obs, *_ = env.step(acts)
+        ref.step(acts)
+    env.close()
+
+
+def test_parallel_dict_view():
+    from pogema_amd import GridConfig, pogema_v0
+    env = pogema_v0(GridConfig(size=8, num_agents=3, obs_radius=2, seed=0, integration="PettingZoo", max_episode_steps=4))
+    obs, infos = env.reset(seed=0)
+    assert list(obs) == ["player_0", "player_1", "player_2"] == env.possible_agents
+    for _ in range(4):
+        obs, rew, term, trunc, infos = env.step({a: 0 for a in env.possible_agents})
+    assert all(trunc.values()) and env.agents == []
+
+
+def test_vec_metrics_tensor():
+    """Batched metrics: rows refresh exactly where episode_done is set."""
+    import torch
+    from pogema_amd import GridConfig, VecPogema
+    env = VecPogema(GridConfig(size=8, num_agents=4, obs_radius=2, density=0.1, seed=0, max_episode_steps=5), batch=64,
+                    auto_reset=True)
+    env.reset(seed=0)
+    for t in range(5):
+        _, _, term, trunc, infos = env.step(torch.randint(0, 5, (64, 4), device="cuda"))
+        done = infos["episode_done"]
+        assert torch.equal(done, term.all(dim=1) | trunc.all(dim=1))
+    assert done.all()  # time limit
+    m = infos["metrics"]
+    assert ((m[:, 0] >= 0) & (m[:, 0] <= 1)).all() and ((m[:, 1] == 0) | (m[:, 1] == 1)).all()
+    assert (m[:, 2] >= 1).all() and (m[:, 2] <= 5).all() and (m[:, 4] <= 5).all()
+    env.close()

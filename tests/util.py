@@ -49,7 +49,9 @@ def oracle_rollout(obstacles, agents, targets, actions, *, obs_radius, collision
         "terminated": np.zeros((T, B, A), bool), "truncated": np.zeros((T, B, A), bool),
         "is_active": np.zeros((T, B, A), bool), "agents_xy": np.zeros((T, B, A, 2), np.int32),
         "targets_xy": np.zeros((T, B, A, 2), np.int32), "elapsed": np.zeros((T, B), np.int32),
+        "episode_done": np.zeros((T, B), bool), "metrics": np.zeros((T, B, 6), np.float32),
     }
+    names = ("ISR", "CSR", "ep_length", "SoC", "makespan", "avg_throughput")
     for t in range(T):
         for b, e in enumerate(envs):
             obs, rew, term, trunc, infos = e.step(actions[t, b])
@@ -58,6 +60,9 @@ def oracle_rollout(obstacles, agents, targets, actions, *, obs_radius, collision
             out["terminated"][t, b] = term
             out["truncated"][t, b] = trunc
             out["is_active"][t, b] = [i["is_active"] for i in infos]
+            if "metrics" in infos[0]:
+                out["episode_done"][t, b] = True
+                out["metrics"][t, b] = [infos[0]["metrics"][k] for k in names]
             st = e.get_state()
             out["agents_xy"][t, b] = st["agents_xy"]
             out["targets_xy"][t, b] = st["targets_xy"]
@@ -80,9 +85,12 @@ def c_oracle_rollout(obstacles, agents, targets, actions, *, obs_radius, collisi
         "terminated": np.zeros((T, B, A), bool), "truncated": np.zeros((T, B, A), bool),
         "is_active": np.zeros((T, B, A), bool), "agents_xy": np.zeros((T, B, A, 2), np.int32),
         "targets_xy": np.zeros((T, B, A, 2), np.int32), "elapsed": np.zeros((T, B), np.int32),
+        "episode_done": np.zeros((T, B), bool), "metrics": np.zeros((T, B, 6), np.float32),
     }
     for t in range(T):
         obs, rew, term, trunc, act = env.step(actions[t], nthreads=nthreads)
+        out["episode_done"][t] = env.episode_done.astype(bool)
+        out["metrics"][t] = np.where(out["episode_done"][t][:, None], env.metrics, 0)
         st = env.get_state()
         out["obs"][t], out["rewards"][t], out["terminated"][t], out["truncated"][t] = obs, rew, term, trunc
         out["is_active"][t] = act
@@ -111,6 +119,7 @@ def engine_rollout(obstacles, agents, targets, actions, *, obs_radius, collision
         "terminated": np.zeros((T, B, A), bool), "truncated": np.zeros((T, B, A), bool),
         "is_active": np.zeros((T, B, A), bool), "agents_xy": np.zeros((T, B, A, 2), np.int32),
         "targets_xy": np.zeros((T, B, A, 2), np.int32), "elapsed": np.zeros((T, B), np.int32),
+        "episode_done": np.zeros((T, B), bool), "metrics": np.zeros((T, B, 6), np.float32),
     }
     tdt = {"int8": torch.int8, "int32": torch.int32, "int64": torch.int64}[action_dtype]
     d_actions = torch.from_numpy(actions).to(device).to(tdt)
@@ -122,6 +131,8 @@ def engine_rollout(obstacles, agents, targets, actions, *, obs_radius, collision
         out["terminated"][t] = term.cpu().numpy()
         out["truncated"][t] = trunc.cpu().numpy()
         out["is_active"][t] = infos["is_active"].cpu().numpy()
+        out["episode_done"][t] = infos["episode_done"].cpu().numpy()
+        out["metrics"][t] = np.where(out["episode_done"][t][:, None], infos["metrics"].cpu().numpy(), 0)
         out["agents_xy"][t] = st["agents_xy"].cpu().numpy()
         out["targets_xy"][t] = st["targets_xy"].cpu().numpy()
         out["elapsed"][t] = st["elapsed"].cpu().numpy()
@@ -132,7 +143,11 @@ def engine_rollout(obstacles, agents, targets, actions, *, obs_radius, collision
 def assert_rollouts_equal(ref, got, what=""):
     """Bit-exact for every integer/bool/index field and for the 0.0/1.0 float planes; rewards within
     1e-6 (BASELINE.json north_star tolerance)."""
-    for key in ("agents_xy", "targets_xy", "elapsed", "terminated", "truncated", "is_active"):
+    if "metrics" in ref and "metrics" in got:  # small-integer arithmetic in float32: exact up to one rounding
+        np.testing.assert_allclose(got["metrics"], ref["metrics"], rtol=1e-6, atol=1e-6, err_msg=f"{what}: metrics")
+    for key in ("agents_xy", "targets_xy", "elapsed", "terminated", "truncated", "is_active", "episode_done"):
+        if key not in ref or key not in got:
+            continue
         if not np.array_equal(ref[key], got[key]):
             bad = np.argwhere(ref[key] != got[key])[0]
             raise AssertionError(f"{what}: {key} differs first at index {tuple(bad)}: "

@@ -371,33 +371,29 @@ __global__ __launch_bounds__((K == 1) ? 64 : 256) void step_kernel(const StepPar
             const bool solved = !group_any<G>(!all_goal_l, gbase);
 #pragma unroll
             for (int s = 0; s < K; ++s) {
-                if (p.on_target == ON_TARGET_FINISH) {
-                    rew[s] = (on_goal[s] && active[s]) ? 1.0f : 0.0f;
-                    term[s] = on_goal[s] ? 1 : 0;
-                    if (on_goal[s]) {  // hide_agent
-                        active[s] = false;
-                        vis[s] = NOCELL_A;
-                    }
-                } else if (p.on_target == ON_TARGET_RESTART) {
-                    rew[s] = (on_goal[s] && active[s]) ? 1.0f : 0.0f;
-                    term[s] = 0;
-                    if (on_goal[s]) {
-                        const int agent = s * 64 + alane;
-                        const size_t gi = (size_t)env * A + agent;
-                        const uint32_t x = (pos[s] >> 16) - r, y = (pos[s] & 0xFFFFu) - r;
-                        const size_t ci = (size_t)env * p.map_cells + (size_t)x * p.map_w + y;
-                        const uint32_t begin = p.comp_begin[ci];
-                        const uint32_t len = p.comp_len[ci];
-                        const uint32_t cnt = p.tcount[gi];
-                        const uint32_t k = lifelong_draw(p.seed, (uint64_t)(p.env_index_base + env),
-                                                         (uint32_t)agent, cnt, len);
-                        const uint32_t cell = p.comp_cells[(size_t)env * p.map_cells + begin + k];
-                        tgt[s] = cell + (((uint32_t)r << 16) | (uint32_t)r);
-                        p.tcount[gi] = cnt + 1;
-                    }
-                } else {
-                    rew[s] = solved ? 1.0f : 0.0f;
-                    term[s] = solved ? 1 : 0;
+                // selects instead of a three-way branch around the per-slot registers: hipcc 7.2 left rew[] of
+                // slots >= 2 undefined on the 'nothing' path of the branchy form (K = 4), see tests four_slots.
+                const bool arrived = on_goal[s] && active[s];
+                const bool coop = p.on_target == ON_TARGET_NOTHING;
+                rew[s] = (coop ? solved : arrived) ? 1.0f : 0.0f;
+                term[s] = (coop ? solved : (p.on_target == ON_TARGET_FINISH && on_goal[s])) ? 1 : 0;
+                if (p.on_target == ON_TARGET_FINISH && on_goal[s]) {  // hide_agent
+                    active[s] = false;
+                    vis[s] = NOCELL_A;
+                }
+                if (p.on_target == ON_TARGET_RESTART && on_goal[s]) {
+                    const int agent = s * 64 + alane;
+                    const size_t gi = (size_t)env * A + agent;
+                    const uint32_t x = (pos[s] >> 16) - r, y = (pos[s] & 0xFFFFu) - r;
+                    const size_t ci = (size_t)env * p.map_cells + (size_t)x * p.map_w + y;
+                    const uint32_t begin = p.comp_begin[ci];
+                    const uint32_t len = p.comp_len[ci];
+                    const uint32_t cnt = p.tcount[gi];
+                    const uint32_t k = lifelong_draw(p.seed, (uint64_t)(p.env_index_base + env),
+                                                     (uint32_t)agent, cnt, len);
+                    const uint32_t cell = p.comp_cells[(size_t)env * p.map_cells + begin + k];
+                    tgt[s] = cell + (((uint32_t)r << 16) | (uint32_t)r);
+                    p.tcount[gi] = cnt + 1;
                 }
                 if (valid[s]) all_term_l = all_term_l && (term[s] != 0);
             }

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpogema_amd.so")
+# PGX_LIB: diagnostic override (A/B of two builds of the SAME engine on one box); never a fallback
+LIB_PATH = os.environ.get("PGX_LIB") or os.path.join(_HERE, "libpogema_amd.so")
 
 PGX_ABI_VERSION = 1
 

@@ -66,11 +66,9 @@ int next_pow2(int v) {
 struct pgx_env {
     pgx_config cfg{};
     int device = 0;
-    int K = 1, G = 64;
+    pgx::StepGeometry geo{};
     int W = 0, PH = 0, PW = 0, wpr = 0, bmw = 0;
-    size_t lds_bytes = 0;
     bool has_state = false;
-    bool p16 = false;
     uint32_t flags = 0;
     // device state
     uint32_t* obst = nullptr;
@@ -119,18 +117,13 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
     e->PW = cfg->width + 2 * r;
     e->wpr = (e->PW + 31) / 32;
     e->bmw = e->PH * e->wpr;
-    if (A <= 64) {
-        e->K = 1;
-        e->G = next_pow2(A);
-    } else {
-        e->K = std::max(2, next_pow2((A + 63) / 64));
-        e->G = 64;
-    }
     if (const char* f = getenv("PGX_FLAGS")) e->flags = (uint32_t)strtoul(f, nullptr, 0);
-    e->p16 = pgx::step_uses_p16(e->K, e->W) && !(e->flags & 2u);  // PGX_FLAGS bit1: force the generic path
-    e->lds_bytes = pgx::step_lds_bytes(e->K, e->G, A, e->bmw, e->W, e->p16);
-    if (e->lds_bytes > 160 * 1024) {
-        const size_t need = e->lds_bytes;
+    int epw_override = 0;  // PGX_EPW: tuning/diagnostic override of the environments-per-wave heuristic
+    if (const char* f = getenv("PGX_EPW")) epw_override = atoi(f);
+    // PGX_FLAGS bit1: force the generic (32-bit row mask) observation path
+    e->geo = pgx::step_geometry(cfg->batch, A, e->bmw, e->W, !(e->flags & 2u), epw_override);
+    if (e->geo.lds_bytes > 160 * 1024) {
+        const size_t need = e->geo.lds_bytes;
         delete e;
         return fail(PGX_E_INVALID,
                     "configuration needs %zu bytes of LDS per workgroup (> 163840): padded bitmaps of %dx%d "
@@ -168,7 +161,12 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
         pgx_destroy(e);
         return fail(err == hipErrorOutOfMemory ? PGX_E_NOMEM : PGX_E_HIP, "hipMalloc failed: %s", msg);
     }
-    if (const char* f = getenv("PGX_FLAGS")) e->flags = (uint32_t)strtoul(f, nullptr, 0);
+    if ((err = pgx::prepare_step(e->geo)) != hipSuccess) {
+        const char* msg = hipGetErrorString(err);
+        const size_t need = e->geo.lds_bytes;
+        pgx_destroy(e);
+        return fail(PGX_E_HIP, "cannot configure the step kernel (%zu bytes of LDS): %s", need, msg);
+    }
     if (e->flags & 4u) {  // diagnostic time stamps, one record per workgroup
         e->dbg_elems = (size_t)cfg->batch * 4;
         if (hipMalloc((void**)&e->dbg, e->dbg_elems * sizeof(unsigned long long)) != hipSuccess) e->dbg = nullptr;
@@ -301,6 +299,7 @@ static void fill_params(const pgx_env* e, pgx::StepParams& p) {
     p.max_steps = c.max_episode_steps;
     p.auto_reset = c.auto_reset;
     p.flags = e->flags;
+    p.epw = e->geo.epw;
     p.seed = c.seed;
     p.env_index_base = c.env_index_base;
     p.obst = e->obst;
@@ -337,7 +336,7 @@ int pgx_step(pgx_env* e, const void* actions, int action_dtype, float* obs, floa
     p.terminated = terminated;
     p.truncated = truncated;
     p.act_out = is_active;
-    PGX_HIP(pgx::launch_step(p, e->K, e->G, e->p16, e->lds_bytes, (hipStream_t)stream));
+    PGX_HIP(pgx::launch_step(p, e->geo, (hipStream_t)stream));
     return PGX_OK;
 }
 
@@ -357,7 +356,7 @@ int pgx_observe(pgx_env* e, float* obs, void* stream) {
     fill_params(e, p);
     p.mode = pgx::MODE_OBSERVE;
     p.obs = obs;
-    PGX_HIP(pgx::launch_step(p, e->K, e->G, e->p16, e->lds_bytes, (hipStream_t)stream));
+    PGX_HIP(pgx::launch_step(p, e->geo, (hipStream_t)stream));
     return PGX_OK;
 }
 

@@ -21,6 +21,7 @@ struct StepParams {
     uint32_t w_magic;  // ceil(2^32 / (2r+1)): exact division of flat window offsets by the window side
     // behaviour
     int32_t mode, collision, on_target, max_steps, auto_reset, action_dtype;
+    int32_t epw;       // environments per wave (single-wave blocks, num_agents <= 64)
     uint32_t flags;    // tuning switches (PGX_FLAGS env var at pgx_create): bit0 = nontemporal obs stores
     uint64_t seed;
     int64_t env_index_base;
@@ -51,9 +52,18 @@ struct StepParams {
     unsigned long long* dbg;  // diagnostic (PGX_FLAGS bit2): per-workgroup {start, resolve done, first store, end} clocks
 };
 
-hipError_t launch_step(const StepParams& p, int K, int G, bool p16, size_t lds_bytes, hipStream_t stream);
-bool step_uses_p16(int K, int W);
-size_t step_lds_bytes(int K, int G, int A, int bmw, int W, bool p16);
+// How one configuration maps onto the step kernel (pgx_kernels.hip: step_geometry()).
+struct StepGeometry {
+    int G;            // lanes per environment group (power of two, 64 when multi_wave)
+    int waves;        // waves per workgroup: 1, or ceil(A / 64) when num_agents > 64
+    int epw;          // environments per wave (1 when multi_wave)
+    bool multi_wave;  // num_agents > 64: one environment per workgroup
+    bool p16;         // window side <= 16: packed 16-bit row masks aliased over the LDS state
+    size_t lds_bytes;
+};
+StepGeometry step_geometry(int batch, int A, int bmw, int W, bool allow_p16, int epw_override);
+hipError_t prepare_step(const StepGeometry& g);
+hipError_t launch_step(const StepParams& p, const StepGeometry& g, hipStream_t stream);
 
 hipError_t launch_pack_obstacles(const uint8_t* obstacles, uint32_t* bm, int batch, int H, int Wd, int r,
                                  int wpr, int bmw, hipStream_t stream);

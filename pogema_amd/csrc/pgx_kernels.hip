@@ -90,80 +90,40 @@ __device__ __forceinline__ bool group_any(bool pred, int gbase) {
     }
 }
 
-// All-pairs sweep of one environment group, branch-free and VALU-only.  For every own agent i
-// (slot s) it min-reduces over all OTHER agents j of the environment:
-//   okey = ((vis_j ^ want_i) << 10) | j              -> okey < 1024  <=> some agent stands on want_i,
-//                                                       and okey is then that agent's index
-//   ckey = ((claim_j ^ want_i) << 10) | ((i-1-j)&1023) -> ckey < 1024 <=> some other agent claims want_i;
-//                                                       ckey < i     <=> a LOWER-index one does, and
-//                                                       i-1-ckey is the largest such index
-template <int K, int G>
-__device__ __forceinline__ void pair_sweep(const uint32_t (&vis)[K], const uint32_t (&claim)[K],
-                                           const uint32_t (&want)[K], int alane, int gbase, int A,
-                                           uint32_t (&okey)[K], uint32_t (&ckey)[K]) {
-#pragma unroll
-    for (int s = 0; s < K; ++s) okey[s] = ckey[s] = KEY_NONE;
-    const int src = gbase + ((alane + 1) & (G - 1));
-#pragma unroll
-    for (int sj = 0; sj < K; ++sj) {
-        if (sj * 64 >= A) break;  // uniform
-        uint32_t cr = vis[sj], dr = claim[sj];
-        if constexpr (K > 1) {  // k = 0: the same lane's agents in the other slots
-#pragma unroll
-            for (int s = 0; s < K; ++s) {
-                if (s == sj) continue;
-                const int i = s * 64 + alane, j = sj * 64 + alane;
-                okey[s] = min(okey[s], ((cr ^ want[s]) << 10) | (uint32_t)j);
-                ckey[s] = min(ckey[s], ((dr ^ want[s]) << 10) | (uint32_t)((i - 1 - j) & 1023));
-            }
-        }
-        for (int k = 1; k < G; ++k) {
-            cr = rot1<G>(cr, src);
-            dr = rot1<G>(dr, src);
-            const int j = sj * 64 + ((alane + k) & (G - 1));
-#pragma unroll
-            for (int s = 0; s < K; ++s) {
-                const int i = s * 64 + alane;
-                okey[s] = min(okey[s], ((cr ^ want[s]) << 10) | (uint32_t)j);
-                ckey[s] = min(ckey[s], ((dr ^ want[s]) << 10) | (uint32_t)((i - 1 - j) & 1023));
-            }
-        }
-    }
+// All-pairs sweep, branch-free and VALU-only.  For the lane's own agent i it min-reduces over the
+// OTHER agents j of the environment:
+//   okey = ((vis_j ^ want_i) << 10) | j                -> okey < 1024 <=> some agent stands on want_i,
+//                                                         and okey is then that agent's index
+//   ckey = ((want_j ^ want_i) << 10) | ((i-1-j)&1023)  -> ckey < 1024 <=> some other agent claims want_i;
+//                                                         ckey < i     <=> a LOWER-index one does, and
+//                                                         i-1-ckey is the largest such index
+__device__ __forceinline__ void pair_min(uint32_t cr, uint32_t dr, uint32_t want, int i, int j, uint32_t& okey,
+                                         uint32_t& ckey) {
+    okey = min(okey, ((cr ^ want) << 10) | (uint32_t)j);
+    ckey = min(ckey, ((dr ^ want) << 10) | (uint32_t)((i - 1 - j) & 1023));
 }
 
-// value of agent idx[s] (same environment) for every own slot; idx < 0 -> `dflt`.
-template <int K, int G>
-__device__ __forceinline__ void group_gather(const uint32_t (&val)[K], const int (&idx)[K], uint32_t dflt, int alane,
-                                             int gbase, int A, uint32_t* s_xchg, uint32_t (&out)[K]) {
-    if constexpr (K == 1) {
-        const int src = gbase + (idx[0] < 0 ? alane : idx[0]);
-        const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)val[0]);
-        out[0] = idx[0] < 0 ? dflt : got;
-    } else {
-#pragma unroll
-        for (int s = 0; s < K; ++s) {
-            const int i = s * 64 + alane;
-            if (i < A) s_xchg[i] = val[s];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int s = 0; s < K; ++s) out[s] = (idx[s] >= 0) ? s_xchg[idx[s]] : dflt;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+// One slot of G partners whose (vis, want) values sit in the lanes of this wave's group: G-1 DPP
+// rotations (plus the unrotated value when the slot belongs to another wave, `with_k0`).
+template <int G>
+__device__ __forceinline__ void sweep_slot(uint32_t cr, uint32_t dr, bool with_k0, int jbase, int alane, int src,
+                                           uint32_t want, int i, uint32_t& okey, uint32_t& ckey) {
+    if (with_k0) pair_min(cr, dr, want, i, jbase + alane, okey, ckey);
+    for (int k = 1; k < G; ++k) {
+        cr = rot1<G>(cr, src);
+        dr = rot1<G>(dr, src);
+        pair_min(cr, dr, want, i, jbase + ((alane + k) & (G - 1)), okey, ckey);
     }
 }
 
 // Workgroup synchronisation that does NOT drain the vector-memory queue.  `__syncthreads()` makes
 // hipcc emit s_waitcnt vmcnt(0) first, i.e. the wave would sit on the acknowledgements of its own
 // state/flag stores -- microseconds under a saturated HBM write stream.  Only LDS traffic has to be
-// ordered here.  K == 1: the block is ONE wave, LDS operations of a wave execute in order, so a
-// compiler-level fence is enough (no s_barrier at all).
-template <int K>
+// ordered here.  Single-wave blocks: LDS operations of a wave execute in order, so a compiler-level
+// fence is enough (no s_barrier at all).
+template <bool MW>
 __device__ __forceinline__ void lds_sync() {
-    if constexpr (K == 1) {
+    if constexpr (!MW) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -175,74 +135,79 @@ __device__ __forceinline__ void lds_sync() {
 }
 
 // ------------------------------------------------------------------------------------------------
-// The step kernel.  K = agents per lane, G = lanes per environment group (power of two).
-//   K == 1 : block = 1 wave, 64/G envs per block.
-//   K  > 1 : block = 4 waves, 1 env per block, G == 64; wave 0 resolves the moves.
+// The step kernel.  One lane = one agent, always.
+//   MW == false : block = 1 wave holding p.epw (<= 64/G) environments of G lanes each (G = next
+//                 power of two >= num_agents <= 64).  Cross-agent traffic is DPP / ds_bpermute only.
+//   MW == true  : num_agents > 64: block = ceil(A/64) waves, one environment per block, wave w owns
+//                 agents [64w, 64w+64).  Every wave resolves its own agents against all A partners
+//                 (partners of other waves come from LDS, then the same DPP rotation), the
+//                 transitive closure and the env-wide reductions go through LDS.
+//   P16         : window side <= 16: row masks are packed to 16 bits, staged through registers and
+//                 written OVER the (by then dead) bitmaps and exchange arrays, so the LDS footprint is
+//                 max(state, rows) and many waves stay resident per CU (DESIGN.md "occupancy").
 // ------------------------------------------------------------------------------------------------
-//   P16    : K == 1 and window side <= 16: row masks are packed to 16 bits, staged through registers
-//            and written OVER the (by then dead) bitmaps -> <= 5 KB of LDS per wave, so that all
-//            32 waves/CU are resident, every wave's loads are issued before the write stream starts
-//            and there is no drain tail (DESIGN.md "occupancy").
-template <int K, int G, bool P16>
-__global__ __launch_bounds__((K == 1) ? 64 : 256) void step_kernel(const StepParams p) {
-    static_assert(!P16 || K == 1, "P16 needs single-wave blocks");
-    constexpr int NT = (K == 1) ? 64 : 256;
-    constexpr int EPW = (K == 1) ? (64 / G) : 1;
+enum { MISC_FLAGS = 0, MISC_ARRIVED = 16, MISC_UNSOLVED = 17, MISC_OFFGOAL = 18, MISC_WORDS = 32 };
+
+template <int G, bool MW, bool P16>
+__global__ __launch_bounds__(MW ? 1024 : 64) void step_kernel(const StepParams p) {
+    static_assert(!MW || G == 64, "multi-wave environments use full waves");
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
 
     const int tid = threadIdx.x;
+    const int NT = MW ? (int)blockDim.x : 64;
     const int lane = tid & 63;
-    const int env0 = blockIdx.x * EPW;
-    const int nenv = min(EPW, p.batch - env0);
+    const int wave = MW ? (tid >> 6) : 0;
+    const int nw = NT >> 6;
+    const int epw = MW ? 1 : p.epw;
+    const int env0 = blockIdx.x * epw;
+    const int nenv = min(epw, p.batch - env0);
     const int A = p.num_agents;
     const int bmw = p.bm_words;
     const int wpr = p.wpr;
     const int r = p.r;
     const int W = 2 * r + 1;
-    const int nag = nenv * A;  // agents handled by this workgroup
+    const int nag = nenv * A;             // agents handled by this workgroup
+    const int AS = MW ? NT : epw * A;     // agent slots in LDS
 
     uint32_t* s_obst = smem;
-    uint32_t* s_occ = s_obst + EPW * bmw;
-    uint32_t* s_apos = s_occ + EPW * bmw;       // [EPW*A]
-    uint32_t* s_atgt = s_apos + EPW * A;        // [EPW*A]
-    uint32_t* s_rows = s_atgt + EPW * A;        // [EPW*A*3*W + 1]
-    uint32_t* s_xchg = s_rows + EPW * A * 3 * W + 1;  // [max(A,1)] cross-lane exchange scratch (K > 1)
+    uint32_t* s_occ = s_obst + epw * bmw;
+    uint32_t* s_apos = s_occ + epw * bmw;  // [AS]
+    uint32_t* s_atgt = s_apos + AS;        // [AS]
+    uint32_t* s_vis = s_atgt + AS;         // MW only: [NT] cells as seen by others
+    uint32_t* s_want = s_vis + (MW ? NT : 0);
+    uint32_t* s_x0 = s_want + (MW ? NT : 0);   // closure exchange, double-buffered
+    uint32_t* s_x1 = s_x0 + (MW ? NT : 0);
+    uint32_t* s_misc = s_x1 + (MW ? NT : 0);   // MW only: round flags + env-wide reductions
+    uint32_t* s_rows = s_misc + (MW ? MISC_WORDS : 0);  // generic path: [nag*3*W + 1] 32-bit row masks
 
     const bool dbg = (p.flags & 4u) && p.dbg;
     if (dbg && tid == 0) p.dbg[(size_t)blockIdx.x * 4 + 0] = wall_clock64();
     // ---- phase 0: issue every global load of the step up front (one exposed HBM latency) ----------
-    const bool resolver = (K == 1) || (tid < 64);
-    const int env_l = (K == 1) ? (lane / G) : 0;
-    const int gbase = (K == 1) ? (lane & ~(G - 1)) : 0;
-    const int alane = (K == 1) ? (lane & (G - 1)) : lane;  // agent index within slot
+    const int env_l = MW ? 0 : (lane / G);
+    const int gbase = MW ? 0 : (lane & ~(G - 1));
+    const int alane = MW ? lane : (lane & (G - 1));
+    const int agent = MW ? tid : alane;
     const bool env_ok = env_l < nenv;
     const int env = env0 + env_l;
+    const bool valid = env_ok && agent < A;
+    const size_t gi = (size_t)env * A + agent;
 
-    uint32_t pos[K], tgt[K];
-    bool valid[K], active[K];
-    int act[K];
-    int elapsed = 0;
-    if (resolver) {
-#pragma unroll
-        for (int s = 0; s < K; ++s) {
-            const int agent = s * 64 + alane;
-            valid[s] = env_ok && agent < A;
-            const size_t gi = (size_t)env * A + agent;
-            pos[s] = valid[s] ? p.pos[gi] : 0u;
-            tgt[s] = valid[s] ? p.tgt[gi] : 1u;
-            active[s] = valid[s] ? (p.active[gi] != 0) : false;
-            int a = 0;
-            if (valid[s] && p.mode == MODE_STEP) {
-                if (p.action_dtype == 0) a = ((const int8_t*)p.actions)[gi];
-                else if (p.action_dtype == 1) a = ((const int32_t*)p.actions)[gi];
-                else a = (int)((const int64_t*)p.actions)[gi];
-            }
-            act[s] = a;
+    uint32_t pos = 0u, tgt = 1u;
+    bool active = false;
+    int act = 0, elapsed = 0;
+    if (valid) {
+        pos = p.pos[gi];
+        tgt = p.tgt[gi];
+        active = p.active[gi] != 0;
+        if (p.mode == MODE_STEP) {
+            if (p.action_dtype == 0) act = ((const int8_t*)p.actions)[gi];
+            else if (p.action_dtype == 1) act = ((const int32_t*)p.actions)[gi];
+            else act = (int)((const int64_t*)p.actions)[gi];
         }
-        if (env_ok && p.mode == MODE_STEP) elapsed = p.elapsed[env];
     }
+    if (env_ok && p.mode == MODE_STEP) elapsed = p.elapsed[env];
     int4 macc = make_int4(0, 0, 0, 0);
-    const bool env_leader = resolver && env_ok && alane == 0 && p.mode == MODE_STEP;
+    const bool env_leader = env_ok && agent == 0 && p.mode == MODE_STEP;
     if (env_leader) macc = p.macc[env];
 
     // ---- phase 1: stage obstacle bitmaps HBM -> LDS, clear the occupancy bitmaps ---------------
@@ -254,19 +219,16 @@ __global__ __launch_bounds__((K == 1) ? 64 : 256) void step_kernel(const StepPar
             s_obst[i] = g[i];
             s_occ[i] = 0u;
         }
+        if (MW && tid < MISC_WORDS) s_misc[tid] = 0u;
     }
-    lds_sync<K>();
+    lds_sync<MW>();
 
-    // ---- phase 2: state update (wave 0) ---------------------------------------------------------
-    if (resolver) {
+    // ---- phase 2: state update ---------------------------------------------------------------------
+    {
         const uint32_t* obm = s_obst + env_l * bmw;
-        uint32_t cur[K], vis[K];  // 22-bit keys: own cell / cell as seen by others (NOCELL_A when hidden)
-#pragma unroll
-        for (int s = 0; s < K; ++s) {
-            if (act[s] < 0 || act[s] > 4) act[s] = 0;
-            cur[s] = to_c22(pos[s]);
-            vis[s] = active[s] ? cur[s] : NOCELL_A;
-        }
+        if (act < 0 || act > 4) act = 0;
+        uint32_t cur = to_c22(pos);                     // 22-bit key of the own cell
+        uint32_t vis = active ? cur : NOCELL_A;         // ... as seen by others (hidden agents stand nowhere)
 
         if (p.mode == MODE_STEP) {
             // ================= move + collision resolve =========================================
@@ -275,158 +237,156 @@ __global__ __launch_bounds__((K == 1) ? 64 : 256) void step_kernel(const StepPar
             // reference are closed-form functions of those two facts plus a transitive closure over
             // "the agent in front of me does not move"; tests/test_parity_gpu.py proves each form
             // equal to the literal sequential / dict-based algorithms of the oracle.
-            uint32_t want[K], okey[K], ckey[K];
-            bool mover[K], blocked[K];
-#pragma unroll
-            for (int s = 0; s < K; ++s) {
-                mover[s] = active[s] && act[s] != 0;
-                const uint32_t d = move_c22(cur[s], act[s]);
-                blocked[s] = mover[s] && bm_test(obm, wpr, from_c22(d));
-                // block_both registers a claim for every active agent (a noop claims its own cell)
-                const bool claims = (p.collision == COLLISION_BLOCK_BOTH) ? active[s] : mover[s];
-                want[s] = claims ? d : NOCELL_B;
-            }
-            pair_sweep<K, G>(vis, want, want, alane, gbase, A, okey, ckey);
-
-            bool stay[K];
-            int nxt[K];
-            if (p.collision == COLLISION_BLOCK_BOTH) {
-                // SURVEY A4: blocked <=> destination is someone's current cell or claimed twice.
-#pragma unroll
-                for (int s = 0; s < K; ++s) {
-                    stay[s] = !mover[s] || blocked[s] || okey[s] < 1024u || ckey[s] < 1024u;
-                    nxt[s] = -1;
+            const bool mover = active && act != 0;
+            const uint32_t d = move_c22(cur, act);
+            const bool blocked = mover && bm_test(obm, wpr, from_c22(d));
+            // block_both registers a claim for every active agent (a noop claims its own cell)
+            const bool claims = (p.collision == COLLISION_BLOCK_BOTH) ? active : mover;
+            const uint32_t want = claims ? d : NOCELL_B;
+            const int i = agent;
+            uint32_t okey = KEY_NONE, ckey = KEY_NONE;
+            const int src = gbase + ((alane + 1) & (G - 1));
+            if constexpr (MW) {
+                s_vis[tid] = vis;
+                s_want[tid] = want;
+                lds_sync<true>();
+                for (int sj = 0; sj < nw; ++sj) {  // wave-uniform
+                    const bool own = (sj == wave);
+                    const uint32_t cr = own ? vis : s_vis[sj * 64 + lane];
+                    const uint32_t dr = own ? want : s_want[sj * 64 + lane];
+                    sweep_slot<64>(cr, dr, !own, sj * 64, lane, src, want, i, okey, ckey);
                 }
             } else {
-#pragma unroll
-                for (int s = 0; s < K; ++s) {
-                    const int i = s * 64 + alane;
-                    const int o = okey[s] < 1024u ? (int)okey[s] : -1;           // agent on my destination
-                    const bool lower = ckey[s] < (uint32_t)i;                    // a lower index claims it too
-                    const int c1 = lower ? (i - 1 - (int)ckey[s]) : -1;          // the largest such index
-                    nxt[s] = mover[s] ? o : -1;
-                    if (p.collision == COLLISION_PRIORITY) {
-                        // SURVEY A3 (agents move one by one in index order).  Agent i ends up moving iff
-                        // its destination is free AT ITS TURN: the occupant o (if any) has a lower index
-                        // and moves away itself, and no claimant j with o < j < i got there first.
-                        stay[s] = !mover[s] || blocked[s] || o > i || c1 > o;
+                sweep_slot<G>(vis, want, false, 0, alane, src, want, i, okey, ckey);
+            }
+
+            bool stay;
+            if (p.collision == COLLISION_BLOCK_BOTH) {
+                // SURVEY A4: blocked <=> destination is someone's current cell or claimed twice.
+                stay = !mover || blocked || okey < 1024u || ckey < 1024u;
+            } else {
+                const int o = okey < 1024u ? (int)okey : -1;           // agent on my destination
+                const bool lower = ckey < (uint32_t)i;                 // a lower index claims it too
+                const int c1 = lower ? (i - 1 - (int)ckey) : -1;       // the largest such index
+                int nxt = mover ? o : -1;
+                if (p.collision == COLLISION_PRIORITY) {
+                    // SURVEY A3 (agents move one by one in index order).  Agent i ends up moving iff
+                    // its destination is free AT ITS TURN: the occupant o (if any) has a lower index
+                    // and moves away itself, and no claimant j with o < j < i got there first.
+                    stay = !mover || blocked || o > i || c1 > o;
+                } else {
+                    // SURVEY A5 'soft' (net effect of the dict/recursion algorithm): the lowest-index
+                    // claimant of a cell is the only candidate; edge swaps stay.
+                    stay = !mover || blocked || lower;
+                    uint32_t want_of_o;
+                    if constexpr (MW) {
+                        want_of_o = nxt >= 0 ? s_want[nxt] : NOCELL_B;
                     } else {
-                        // SURVEY A5 'soft' (net effect of the dict/recursion algorithm): the lowest-index
-                        // claimant of a cell is the only candidate; edge swaps stay (resolved below).
-                        stay[s] = !mover[s] || blocked[s] || lower;
+                        const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute((gbase + (nxt < 0 ? alane : nxt)) << 2, (int)want);
+                        want_of_o = nxt >= 0 ? got : NOCELL_B;
                     }
-                }
-                if (p.collision == COLLISION_SOFT) {
-                    uint32_t want_of_o[K];
-                    group_gather<K, G>(want, nxt, NOCELL_B, alane, gbase, A, s_xchg, want_of_o);
-#pragma unroll
-                    for (int s = 0; s < K; ++s) stay[s] = stay[s] || (want_of_o[s] == cur[s]);  // edge swap
+                    stay = stay || (want_of_o == cur);  // edge swap
                 }
                 // transitive closure of "the agent on my destination stays": pointer doubling, at most
-                // ceil(log2 A) rounds, usually 1-3 (exit as soon as every chain in the wave has ended).
+                // ceil(log2 A) rounds, usually 1-3 (exit as soon as every chain of the workgroup has ended).
                 int rounds = 1;
                 while ((1 << rounds) < A) ++rounds;
                 for (int it = 0; it < rounds; ++it) {
-                    bool open = false;
-#pragma unroll
-                    for (int s = 0; s < K; ++s) open = open || (nxt[s] >= 0 && !stay[s]);
-                    if (__ballot(open) == 0ull) break;
-                    uint32_t packed[K], got[K];
-#pragma unroll
-                    for (int s = 0; s < K; ++s) packed[s] = (stay[s] ? 0x80000000u : 0u) | (uint32_t)(nxt[s] + 1);
-                    group_gather<K, G>(packed, nxt, 0u, alane, gbase, A, s_xchg, got);
-#pragma unroll
-                    for (int s = 0; s < K; ++s) {
-                        if (nxt[s] >= 0) {
-                            stay[s] = stay[s] || (got[s] >> 31);
-                            nxt[s] = (int)(got[s] & 0x7FFFFFFFu) - 1;
-                        }
+                    const bool open = nxt >= 0 && !stay;
+                    const uint32_t packed = (stay ? 0x80000000u : 0u) | (uint32_t)(nxt + 1);
+                    uint32_t got;
+                    if constexpr (MW) {
+                        uint32_t* buf = (it & 1) ? s_x1 : s_x0;
+                        buf[tid] = packed;
+                        if (__ballot(open) != 0ull && lane == 0) s_misc[MISC_FLAGS + it] = 1u;
+                        lds_sync<true>();
+                        if (s_misc[MISC_FLAGS + it] == 0u) break;  // block-uniform
+                        got = nxt >= 0 ? buf[nxt] : 0u;
+                    } else {
+                        if (__ballot(open) == 0ull) break;
+                        got = (uint32_t)__builtin_amdgcn_ds_bpermute((gbase + (nxt < 0 ? alane : nxt)) << 2, (int)packed);
+                    }
+                    if (nxt >= 0) {
+                        stay = stay || (got >> 31);
+                        nxt = (int)(got & 0x7FFFFFFFu) - 1;
                     }
                 }
             }
-#pragma unroll
-            for (int s = 0; s < K; ++s) {
-                if (!stay[s]) {
-                    cur[s] = want[s];
-                    vis[s] = want[s];
-                    pos[s] = from_c22(want[s]);
-                }
+            if (!stay) {
+                cur = want;
+                vis = want;
+                pos = from_c22(want);
             }
 
             // ================= goals, rewards, done flags ==========
-            bool on_goal[K];
-            bool all_goal_l = true, all_term_l = true;
-            float rew[K];
-            uint8_t term[K];
-            int n_arrived = 0;  // `was_on_goal` of the reference: on goal and still active right after the moves
-#pragma unroll
-            for (int s = 0; s < K; ++s) {
-                on_goal[s] = valid[s] && pos[s] == tgt[s];
-                if (valid[s]) all_goal_l = all_goal_l && on_goal[s] && active[s];
-                const unsigned long long m = __ballot(on_goal[s] && active[s]);
-                if constexpr (G == 64) n_arrived += __popcll(m);
-                else n_arrived += __popcll((m >> gbase) & ((1ull << G) - 1ull));
-            }
-            // env-wide AND (all lanes of the group; invalid lanes contribute true)
-            const bool solved = !group_any<G>(!all_goal_l, gbase);
-#pragma unroll
-            for (int s = 0; s < K; ++s) {
-                // selects instead of a three-way branch around the per-slot registers: hipcc 7.2 left rew[] of
-                // slots >= 2 undefined on the 'nothing' path of the branchy form (K = 4), see tests four_slots.
-                const bool arrived = on_goal[s] && active[s];
-                const bool coop = p.on_target == ON_TARGET_NOTHING;
-                rew[s] = (coop ? solved : arrived) ? 1.0f : 0.0f;
-                term[s] = (coop ? solved : (p.on_target == ON_TARGET_FINISH && on_goal[s])) ? 1 : 0;
-                if (p.on_target == ON_TARGET_FINISH && on_goal[s]) {  // hide_agent
-                    active[s] = false;
-                    vis[s] = NOCELL_A;
+            const bool on_goal = valid && pos == tgt;
+            const bool arrived = on_goal && active;  // `was_on_goal` of the reference
+            int n_arrived;
+            bool solved, all_on_goal;
+            if constexpr (MW) {
+                const unsigned long long ma = __ballot(arrived);
+                const unsigned long long mu = __ballot(valid && !arrived);
+                const unsigned long long mo = __ballot(valid && !on_goal);
+                if (lane == 0) {
+                    if (ma) atomicAdd(&s_misc[MISC_ARRIVED], (uint32_t)__popcll(ma));
+                    if (mu) s_misc[MISC_UNSOLVED] = 1u;
+                    if (mo) s_misc[MISC_OFFGOAL] = 1u;
                 }
-                if (p.on_target == ON_TARGET_RESTART && on_goal[s]) {
-                    const int agent = s * 64 + alane;
-                    const size_t gi = (size_t)env * A + agent;
-                    const uint32_t x = (pos[s] >> 16) - r, y = (pos[s] & 0xFFFFu) - r;
-                    const size_t ci = (size_t)env * p.map_cells + (size_t)x * p.map_w + y;
-                    const uint32_t begin = p.comp_begin[ci];
-                    const uint32_t len = p.comp_len[ci];
-                    const uint32_t cnt = p.tcount[gi];
-                    const uint32_t k = lifelong_draw(p.seed, (uint64_t)(p.env_index_base + env),
-                                                     (uint32_t)agent, cnt, len);
-                    const uint32_t cell = p.comp_cells[(size_t)env * p.map_cells + begin + k];
-                    tgt[s] = cell + (((uint32_t)r << 16) | (uint32_t)r);
-                    p.tcount[gi] = cnt + 1;
-                }
-                if (valid[s]) all_term_l = all_term_l && (term[s] != 0);
+                lds_sync<true>();
+                n_arrived = (int)s_misc[MISC_ARRIVED];
+                solved = s_misc[MISC_UNSOLVED] == 0u;
+                all_on_goal = s_misc[MISC_OFFGOAL] == 0u;
+            } else {
+                const unsigned long long ma = __ballot(arrived);
+                if constexpr (G == 64) n_arrived = __popcll(ma);
+                else n_arrived = __popcll((ma >> gbase) & ((1ull << G) - 1ull));
+                solved = !group_any<G>(valid && !arrived, gbase);
+                all_on_goal = !group_any<G>(valid && !on_goal, gbase);
             }
-            const bool all_term = !group_any<G>(!all_term_l, gbase);
+            const bool coop = p.on_target == ON_TARGET_NOTHING;
+            const bool fin = p.on_target == ON_TARGET_FINISH;
+            const float rew = (coop ? solved : arrived) ? 1.0f : 0.0f;
+            const uint8_t term = (coop ? solved : (fin && on_goal)) ? 1 : 0;
+            const bool all_term = coop ? solved : (fin && all_on_goal);
+            if (fin && on_goal) {  // hide_agent
+                active = false;
+                vis = NOCELL_A;
+            }
+            if (p.on_target == ON_TARGET_RESTART && on_goal) {
+                const uint32_t x = (pos >> 16) - r, y = (pos & 0xFFFFu) - r;
+                const size_t ci = (size_t)env * p.map_cells + (size_t)x * p.map_w + y;
+                const uint32_t begin = p.comp_begin[ci];
+                const uint32_t len = p.comp_len[ci];
+                const uint32_t cnt = p.tcount[gi];
+                const uint32_t k = lifelong_draw(p.seed, (uint64_t)(p.env_index_base + env), (uint32_t)agent, cnt, len);
+                const uint32_t cell = p.comp_cells[(size_t)env * p.map_cells + begin + k];
+                tgt = cell + (((uint32_t)r << 16) | (uint32_t)r);
+                p.tcount[gi] = cnt + 1;
+            }
             elapsed += 1;
             const bool trunc = p.max_steps > 0 && elapsed >= p.max_steps;
             const bool do_reset = p.auto_reset && (all_term || trunc);
-#pragma unroll
-            for (int s = 0; s < K; ++s) {
-                if (valid[s]) {
-                    const int agent = s * 64 + alane;
-                    const size_t gi = (size_t)env * A + agent;
-                    p.rewards[gi] = rew[s];
-                    p.terminated[gi] = term[s];
-                    p.truncated[gi] = trunc ? 1 : 0;
-                    if (p.act_out) p.act_out[gi] = active[s] ? 1 : 0;
-                    if (do_reset) {  // auto-reset wrapper: observation comes from the reset state
-                        pos[s] = p.pos0[gi];
-                        tgt[s] = p.tgt0[gi];
-                        active[s] = true;
-                        vis[s] = to_c22(pos[s]);
-                    }
-                    p.pos[gi] = pos[s];
-                    p.tgt[gi] = tgt[s];
-                    p.active[gi] = active[s] ? 1 : 0;
+            if (valid) {
+                p.rewards[gi] = rew;
+                p.terminated[gi] = term;
+                p.truncated[gi] = trunc ? 1 : 0;
+                if (p.act_out) p.act_out[gi] = active ? 1 : 0;
+                if (do_reset) {  // auto-reset wrapper: observation comes from the reset state
+                    pos = p.pos0[gi];
+                    tgt = p.tgt0[gi];
+                    active = true;
+                    vis = to_c22(pos);
                 }
+                p.pos[gi] = pos;
+                p.tgt[gi] = tgt;
+                p.active[gi] = active ? 1 : 0;
             }
             if (env_leader) {
                 p.elapsed[env] = do_reset ? 0 : elapsed;
                 // ---- metric wrappers, fused: per-env accumulators, emitted when the episode finishes ----
                 const bool finished = all_term || trunc;
                 const int step = elapsed - 1;
-                if (p.on_target == ON_TARGET_FINISH) {
+                if (fin) {
                     macc.x += n_arrived;
                     macc.y += n_arrived * step;
                     if (n_arrived) macc.z = max(macc.z, step);
@@ -436,13 +396,13 @@ __global__ __launch_bounds__((K == 1) ? 64 : 256) void step_kernel(const StepPar
                 if (finished && p.metrics_out) {
                     float* mo = p.metrics_out + (size_t)env * 6;
                     const float fA = (float)A;
-                    if (p.on_target == ON_TARGET_FINISH) {
+                    if (fin) {
                         const int unsolved = A - macc.x;
                         const int total = macc.y + unsolved * step;
                         const int mx = unsolved ? step : macc.z;
                         mo[0] = (float)macc.x / fA; mo[1] = macc.x == A ? 1.0f : 0.0f; mo[2] = (float)total / fA + 1.0f;
                         mo[3] = (float)(total + A); mo[4] = (float)(mx + 1); mo[5] = 0.0f;
-                    } else if (p.on_target == ON_TARGET_NOTHING) {
+                    } else if (coop) {
                         mo[0] = (float)n_arrived / fA; mo[1] = n_arrived == A ? 1.0f : 0.0f; mo[2] = (float)(step + 1);
                         mo[3] = (float)(A * (step + 1)); mo[4] = (float)(step + 1); mo[5] = 0.0f;
                     } else {
@@ -457,38 +417,33 @@ __global__ __launch_bounds__((K == 1) ? 64 : 256) void step_kernel(const StepPar
         }
 
         // ---- publish agent cells to LDS and rebuild the occupancy bitmap ------------------------
-        if (p.obs) {
-#pragma unroll
-            for (int s = 0; s < K; ++s) {
-                if (valid[s]) {
-                    const int la = env_l * A + s * 64 + alane;
-                    s_apos[la] = pos[s];
-                    s_atgt[la] = tgt[s];
-                    if (vis[s] != NOCELL_A) {
-                        const uint32_t x = pos[s] >> 16, y = pos[s] & 0xFFFFu;
-                        atomicOr(&s_occ[env_l * bmw + x * wpr + (y >> 5)], 1u << (y & 31));
-                    }
-                }
+        if (p.obs && valid) {
+            const int la = MW ? tid : (env_l * A + alane);
+            s_apos[la] = pos;
+            s_atgt[la] = tgt;
+            if (vis != NOCELL_A) {
+                const uint32_t x = pos >> 16, y = pos & 0xFFFFu;
+                atomicOr(&s_occ[env_l * bmw + x * wpr + (y >> 5)], 1u << (y & 31));
             }
         }
     }
     if (dbg && tid == 0) p.dbg[(size_t)blockIdx.x * 4 + 1] = wall_clock64();
     if (!p.obs) return;
-    lds_sync<K>();
+    lds_sync<MW>();
 
     if constexpr (P16) {
-        // ---- phase 3 (P16): row masks -> registers -> (sync) -> packed u16 rows over the bitmaps -------
+        // ---- phase 3 (P16): row masks -> registers -> (sync) -> packed u16 rows over the dead state -------
         const uint32_t wmask = (1u << W) - 1u;
-        uint32_t rp[3][8];  // 16 rows x 16 bit per item, 3 items per lane (nag * 3 <= 192)
+        uint32_t rp[3][8];  // 16 rows x 16 bit per item, 3 items per lane (nag * 3 <= 3 * NT)
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
 #pragma unroll
             for (int m = 0; m < 8; ++m) rp[t][m] = 0u;
-            const int item = tid + t * 64;
+            const int item = tid + t * NT;
             if (item < nag * 3) {
                 const int la = item / 3;
                 const int c = item - la * 3;
-                const int el = la / A;
+                const int el = MW ? 0 : (la / A);
                 const uint32_t cell = s_apos[la];
                 const int x = (int)(cell >> 16), y = (int)(cell & 0xFFFFu);
                 if (c < 2) {
@@ -507,6 +462,7 @@ __global__ __launch_bounds__((K == 1) ? 64 : 256) void step_kernel(const StepPar
                         }
                     }
                 } else {
+                    // get_square_target: per-axis clamp of the offset to the window edge
                     const uint32_t tc = s_atgt[la];
                     int dx = x - (int)(tc >> 16), dy = y - (int)(tc & 0xFFFFu);
                     dx = max(-r, min(r, dx));
@@ -518,11 +474,11 @@ __global__ __launch_bounds__((K == 1) ? 64 : 256) void step_kernel(const StepPar
                 }
             }
         }
-        lds_sync<K>();  // every lane has read the bitmaps / agent cells: the region may be overwritten
+        lds_sync<MW>();  // every lane has read the bitmaps / agent cells: the region may be overwritten
         uint16_t* rows16 = reinterpret_cast<uint16_t*>(smem);
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-            const int item = tid + t * 64;
+            const int item = tid + t * NT;
             if (item < nag * 3) {
 #pragma unroll
                 for (int wy = 0; wy < 16; ++wy)
@@ -530,7 +486,7 @@ __global__ __launch_bounds__((K == 1) ? 64 : 256) void step_kernel(const StepPar
             }
         }
         if (tid < 4) rows16[nag * 3 * W + tid] = 0;
-        lds_sync<K>();
+        lds_sync<MW>();
 
         // ---- phase 4 (P16): stream the float32 observations ----------------------------------------------
         const int n = nag * 3 * W * W;
@@ -553,12 +509,12 @@ __global__ __launch_bounds__((K == 1) ? 64 : 256) void step_kernel(const StepPar
         typedef float f32x4 __attribute__((ext_vector_type(4)));
         f32x4* out4 = reinterpret_cast<f32x4*>(out + head);
         const uint32_t* rows32 = smem;
-        // flat float offset e0 = head + 4q advances by 256 per iteration: keep (row, col) incrementally
+        // flat float offset e0 = head + 4q advances by 4*NT per iteration: keep (row, col) incrementally
         int e0 = head + (tid << 2);
         int row = (int)__umulhi((uint32_t)e0, magic);
         int col = e0 - row * W;
-        const int drow = 256 / W, dcol = 256 - drow * W;
-        for (int q = tid; q < nvec; q += 64) {
+        const int drow = (4 * NT) / W, dcol = 4 * NT - drow * W;
+        for (int q = tid; q < nvec; q += NT) {
             const uint32_t w0 = rows32[row >> 1], w1 = rows32[(row >> 1) + 1];
             const uint32_t pair = (uint32_t)((((uint64_t)w1 << 32) | w0) >> (16 * (row & 1)));  // row | row+1 << 16
             const uint32_t b = ((pair & 0xFFFFu) >> col) | ((pair >> 16) << (W - col));
@@ -589,7 +545,7 @@ __global__ __launch_bounds__((K == 1) ? 64 : 256) void step_kernel(const StepPar
         for (int item = tid; item < nag * 3; item += NT) {
             const int la = item / 3;
             const int c = item - la * 3;
-            const int el = (K == 1) ? (la / A) : 0;
+            const int el = MW ? 0 : (la / A);
             const uint32_t cell = s_apos[la];
             const int x = (int)(cell >> 16), y = (int)(cell & 0xFFFFu);
             uint32_t* out = s_rows + item * W;
@@ -605,7 +561,6 @@ __global__ __launch_bounds__((K == 1) ? 64 : 256) void step_kernel(const StepPar
                     out[wy] = (uint32_t)(both >> sh) & wmask;
                 }
             } else {
-                // get_square_target: per-axis clamp of the offset to the window edge
                 const uint32_t t = s_atgt[la];
                 int dx = x - (int)(t >> 16), dy = y - (int)(t & 0xFFFFu);
                 dx = max(-r, min(r, dx));
@@ -617,7 +572,7 @@ __global__ __launch_bounds__((K == 1) ? 64 : 256) void step_kernel(const StepPar
         }
         if (tid == 0) s_rows[nag * 3 * W] = 0u;
     }
-    lds_sync<K>();
+    lds_sync<MW>();
 
     // ---- phase 4: stream the float32 observations, 16 bytes per lane per store ---------------------
     {
@@ -626,7 +581,7 @@ __global__ __launch_bounds__((K == 1) ? 64 : 256) void step_kernel(const StepPar
         float* out = p.obs + base;
         const int head = min(n, (int)((4 - (base & 3)) & 3));
         const uint32_t magic = p.w_magic;  // ceil(2^32 / W)
-        // unaligned head / tail (only when A*3*W*W*EPW is not a multiple of 4)
+        // unaligned head / tail (only when the workgroup's float count is not a multiple of 4)
         const int nvec = (n - head) >> 2;
         const int tail0 = head + (nvec << 2);
         if (tid < 8) {
@@ -745,54 +700,73 @@ __global__ void occupancy_kernel(const uint32_t* __restrict__ pos, const uint8_t
 // ------------------------------------------------------------------------------------------------
 // host-side launch helpers (called from pgx_api.cpp through pgx_internal.h)
 // ------------------------------------------------------------------------------------------------
-template <int K, int G, bool P16>
-static hipError_t launch_step_t(const StepParams& p, size_t lds_bytes, hipStream_t stream) {
-    constexpr int NT = (K == 1) ? 64 : 256;
-    constexpr int EPW = (K == 1) ? (64 / G) : 1;
-    const int blocks = (p.batch + EPW - 1) / EPW;
-    if (lds_bytes > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<K, G, P16>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL((step_kernel<K, G, P16>), dim3(blocks), dim3(NT), lds_bytes, stream, p);
-    return hipGetLastError();
-}
+template <int G, bool MW, bool P16>
+static const void* step_fn() { return reinterpret_cast<const void*>(&step_kernel<G, MW, P16>); }
 
-hipError_t launch_step(const StepParams& p, int K, int G, bool p16, size_t lds_bytes, hipStream_t stream) {
-    if (K == 1) {
-#define PGX_CASE(g)                                                        \
-    case g:                                                                \
-        return p16 ? launch_step_t<1, g, true>(p, lds_bytes, stream)       \
-                   : launch_step_t<1, g, false>(p, lds_bytes, stream);
-        switch (G) {
-            PGX_CASE(1) PGX_CASE(2) PGX_CASE(4) PGX_CASE(8) PGX_CASE(16) PGX_CASE(32) PGX_CASE(64)
-            default: return hipErrorInvalidValue;
-        }
+static const void* step_fn_for(const StepGeometry& g) {
+    if (g.multi_wave) return g.p16 ? step_fn<64, true, true>() : step_fn<64, true, false>();
+#define PGX_CASE(gg) case gg: return g.p16 ? step_fn<gg, false, true>() : step_fn<gg, false, false>();
+    switch (g.G) {
+        PGX_CASE(1) PGX_CASE(2) PGX_CASE(4) PGX_CASE(8) PGX_CASE(16) PGX_CASE(32) PGX_CASE(64)
+        default: return nullptr;
+    }
 #undef PGX_CASE
-    }
-    switch (K) {
-        case 2: return launch_step_t<2, 64, false>(p, lds_bytes, stream);
-        case 4: return launch_step_t<4, 64, false>(p, lds_bytes, stream);
-        case 8: return launch_step_t<8, 64, false>(p, lds_bytes, stream);
-        case 16: return launch_step_t<16, 64, false>(p, lds_bytes, stream);
-        default: return hipErrorInvalidValue;
-    }
 }
 
-bool step_uses_p16(int K, int W) { return K == 1 && W <= 16; }
-
-size_t step_lds_bytes(int K, int G, int A, int bmw, int W, bool p16) {
-    const int EPW = (K == 1) ? (64 / G) : 1;
-    const size_t state_words = (size_t)2 * EPW * bmw + (size_t)2 * EPW * A;  // bitmaps + agent cells
+// G, waves per block, envs per wave, P16 and the LDS footprint for one configuration.
+//   epw_override > 0 forces the number of environments per wave (A <= 32 only; clamped to 64/G).
+StepGeometry step_geometry(int batch, int A, int bmw, int W, bool allow_p16, int epw_override) {
+    StepGeometry g{};
+    g.multi_wave = A > 64;
+    g.G = 64;
+    if (!g.multi_wave) {
+        g.G = 1;
+        while (g.G < A) g.G <<= 1;
+    }
+    g.waves = g.multi_wave ? (A + 63) / 64 : 1;
+    const int max_epw = g.multi_wave ? 1 : 64 / g.G;
+    g.epw = max_epw;
+    if (!g.multi_wave) {
+        // Fewer environments per wave = more, shorter waves: every wave's prologue (loads, bitmap staging,
+        // collision sweep) overlaps with other waves' observation streams, and small launches still cover
+        // the 256 CUs.  Measured (profiles/r1/epw_sweep.txt): best while the launch stays within ~4 rounds
+        // of the 8192 resident waves; beyond that the per-wave fixed cost shows (A = 8: +16 % at 65536 waves).
+        while (g.epw > 1 && (batch + g.epw / 2 - 1) / (g.epw / 2) <= 32768) g.epw >>= 1;
+        if (epw_override > 0) g.epw = epw_override < max_epw ? epw_override : max_epw;
+    }
+    g.p16 = allow_p16 && W <= 16;
+    const int NT = 64 * g.waves;
+    const size_t agent_slots = g.multi_wave ? (size_t)NT : (size_t)g.epw * A;
+    size_t state_words = (size_t)2 * g.epw * bmw + 2 * agent_slots;
+    if (g.multi_wave) state_words += (size_t)4 * NT + MISC_WORDS;
+    const size_t nag = (size_t)g.epw * A;
     size_t bytes;
-    if (p16) {
-        const size_t rows_bytes = ((size_t)EPW * A * 3 * W + 4) * 2;  // u16 rows alias the state region
+    if (g.p16) {
+        const size_t rows_bytes = (nag * 3 * W + 4) * 2;  // u16 rows alias the whole state region
         bytes = state_words * 4 > rows_bytes ? state_words * 4 : rows_bytes;
     } else {
-        bytes = (state_words + (size_t)EPW * A * 3 * W + 1 + (size_t)(A > 0 ? A : 1)) * 4;
+        bytes = (state_words + nag * 3 * W + 1) * 4;
     }
-    return (bytes + 15) & ~(size_t)15;
+    g.lds_bytes = (bytes + 15) & ~(size_t)15;
+    return g;
+}
+
+// once per handle (NOT per launch: keeps pgx_step capturable in a HIP graph)
+hipError_t prepare_step(const StepGeometry& g) {
+    const void* fn = step_fn_for(g);
+    if (!fn) return hipErrorInvalidValue;
+    if (g.lds_bytes > 48 * 1024)
+        return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+    return hipSuccess;
+}
+
+hipError_t launch_step(const StepParams& p, const StepGeometry& g, hipStream_t stream) {
+    const void* fn = step_fn_for(g);
+    if (!fn) return hipErrorInvalidValue;
+    const int blocks = g.multi_wave ? p.batch : (p.batch + g.epw - 1) / g.epw;
+    StepParams args = p;
+    void* kargs[] = {&args};
+    return hipLaunchKernel(fn, dim3(blocks), dim3(64 * g.waves), kargs, g.lds_bytes, stream);
 }
 
 hipError_t launch_pack_obstacles(const uint8_t* obstacles, uint32_t* bm, int batch, int H, int Wd, int r,

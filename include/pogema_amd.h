@@ -100,9 +100,30 @@ int64_t pgx_agent_elems(const pgx_env* env); /* batch * agents                  
  *   agent_xy   device i32 [batch, agents, 2]       unpadded (row, col)
  *   target_xy  device i32 [batch, agents, 2]
  * The state is also stored as the auto-reset state.  For on_target = RESTART this call additionally
- * labels connected components on the host (it synchronises `stream`); otherwise it is async. */
+ * builds the component tables on the device.  Asynchronous on `stream`. */
 int pgx_reset_from_state(pgx_env* env, const uint8_t* obstacles, const int32_t* agent_xy,
                          const int32_t* target_xy, void* stream);
+
+/* On-device reset: draws the instances on the GPU.  Replaces `Grid.__init__` with a random map: upstream
+ * pogema/generator.py `generate_obstacles` (Bernoulli(density) obstacles), the BFS component labelling and
+ * `generate_positions_and_targets_fast` (starts/targets on distinct free cells, each pair inside one
+ * 4-connected component) -- SURVEY L1 / section 8f rank 2 -- plus, for on_target = RESTART, the component
+ * tables `PogemaLifeLong` draws new targets from.  The random stream is this build's own counter-based
+ * generator (numpy's PCG64 is not reproduced -- DESIGN.md); pgx_generate draws the SAME instances on the
+ * host.  Env i of the shard draws instance (seed + env_index_base + i).
+ *   shared_map  device u8 [height, width] or NULL   given map for every env (GridConfig.map): only
+ *                                                   starts/targets are drawn, `density` is ignored
+ *   env_mask    device u8 [batch] or NULL           NULL: every env, generation 0 (a pure function of
+ *                                                   seed and env index).  Otherwise only the flagged envs
+ *                                                   get a NEW instance (their generation counter advances);
+ *                                                   their step counters and metric accumulators restart.
+ * Synchronises `stream` (the retry decision needs the device's failure count).  Returns
+ * PGX_E_PLACEMENT if an env cannot be filled after `max_retries` re-draws (<= 0: 10). */
+int pgx_reset_random(pgx_env* env, float density, uint64_t seed, const uint8_t* shared_map,
+                     const uint8_t* env_mask, int32_t max_retries, void* stream);
+
+/* The unpadded obstacle maps currently installed: device u8 [batch, height, width] (`Grid.get_obstacles`). */
+int pgx_get_map(pgx_env* env, uint8_t* obstacles, void* stream);
 
 /* ---- the hot path ------------------------------------------------------------------------------- */
 /* One environment step for every env of the shard.  Replaces, per env, `Pogema.step` /

@@ -505,3 +505,97 @@ int po_get_state(const po_env* e, int32_t* agent_xy, int32_t* target_xy, uint8_t
     if (occupancy) memcpy(occupancy, e->occ, (size_t)e->c.batch * e->PH * e->PW);
     return 0;
 }
+
+/* ================================================================================================
+ * Instance generator "GEN v2" -- plain-C port of oracle/generator_oracle.py (the normative statement).
+ * Test infrastructure like everything else here; the product's generators (host pgx_generate, device
+ * pgx_reset_random) are compared against it.  Returns 0, or -5 when an env could not be filled.
+ *   obstacles  u8  [batch, H, W]   output, or input [H, W] shared by every env when given_map != 0
+ *   agent_xy / target_xy   i32 [batch, A, 2] output
+ * ================================================================================================ */
+#define PO_TAG_OBST 0x4F42535400000000ull
+#define PO_TAG_PLACE 0x504C414300000000ull
+
+static uint64_t po_instance_hash(uint64_t seed, uint64_t env, uint32_t epoch, uint32_t attempt) {
+    uint64_t h = splitmix64(seed);
+    h = splitmix64(h ^ env);
+    return splitmix64(h ^ (((uint64_t)epoch << 32) | attempt));
+}
+
+static void po_min_index_labels(const uint8_t* obst, int H, int W, int32_t* label, int32_t* stack) {
+    const int cells = H * W;
+    for (int c = 0; c < cells; ++c) label[c] = -1;
+    for (int s = 0; s < cells; ++s) {
+        if (obst[s] || label[s] >= 0) continue;
+        int sp = 0;
+        label[s] = s;
+        stack[sp++] = s;
+        while (sp) {
+            const int c = stack[--sp];
+            const int x = c / W, y = c % W;
+            const int nb[4] = {x > 0 ? c - W : -1, x + 1 < H ? c + W : -1, y > 0 ? c - 1 : -1, y + 1 < W ? c + 1 : -1};
+            for (int k = 0; k < 4; ++k) {
+                const int n = nb[k];
+                if (n >= 0 && !obst[n] && label[n] < 0) {
+                    label[n] = s;
+                    stack[sp++] = n;
+                }
+            }
+        }
+    }
+}
+
+int po_generate(int32_t batch, int32_t H, int32_t W, int32_t A, float density, uint64_t seed, int64_t env_index_base,
+                const uint32_t* epochs, int32_t max_retries, int32_t given_map, uint8_t* obstacles, int32_t* agent_xy,
+                int32_t* target_xy) {
+    const int cells = H * W;
+    if (2 * (int64_t)A > cells) return -5;
+    double thr_d = (double)density * 16777216.0 + 0.5;
+    if (thr_d < 0) thr_d = 0;
+    if (thr_d > 16777216.0) thr_d = 16777216.0;
+    const uint32_t thr = (uint32_t)thr_d;
+    int status = 0;
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int b = 0; b < batch; ++b) {
+        int32_t* label = (int32_t*)malloc(sizeof(int32_t) * cells);
+        int32_t* stack = (int32_t*)malloc(sizeof(int32_t) * cells);
+        int32_t* pending = (int32_t*)malloc(sizeof(int32_t) * cells);
+        uint8_t* taken = (uint8_t*)malloc(cells);
+        uint8_t* obst = given_map ? obstacles : obstacles + (size_t)b * cells;
+        int32_t* axy = agent_xy + (size_t)b * A * 2;
+        int32_t* txy = target_xy + (size_t)b * A * 2;
+        int ok = 0;
+        for (int attempt = 0; attempt < max_retries && !ok; ++attempt) {
+            const uint64_t h = po_instance_hash(seed, (uint64_t)(env_index_base + b), epochs ? epochs[b] : 0u, (uint32_t)attempt);
+            if (!given_map)
+                for (int c = 0; c < cells; ++c) obst[c] = (splitmix64(h ^ (PO_TAG_OBST | (uint64_t)c)) >> 40) < thr ? 1 : 0;
+            if (!given_map || attempt == 0) po_min_index_labels(obst, H, W, label, stack);
+            memset(taken, 0, cells);
+            for (int c = 0; c < cells; ++c) pending[c] = -1;
+            int placed = 0;
+            const uint32_t budget = 32u * (uint32_t)cells + 64u;
+            for (uint32_t t = 0; t < budget && placed < A; ++t) {
+                const uint32_t c = (uint32_t)(((splitmix64(h ^ (PO_TAG_PLACE | (uint64_t)t)) >> 32) * (uint64_t)cells) >> 32);
+                if (obst[c] || taken[c]) continue;
+                taken[c] = 1;
+                const int root = label[c];
+                if (pending[root] < 0) {
+                    pending[root] = (int32_t)c;
+                } else {
+                    const int s = pending[root];
+                    pending[root] = -1;
+                    axy[2 * placed] = s / W; axy[2 * placed + 1] = s % W;
+                    txy[2 * placed] = (int32_t)c / W; txy[2 * placed + 1] = (int32_t)c % W;
+                    ++placed;
+                }
+            }
+            ok = placed == A;
+        }
+        if (!ok) {
+#pragma omp critical
+            status = -5;
+        }
+        free(label); free(stack); free(pending); free(taken);
+    }
+    return status;
+}

@@ -81,6 +81,13 @@ struct pgx_env {
     unsigned long long* dbg = nullptr;
     size_t dbg_elems = 0;
     uint32_t *comp_begin = nullptr, *comp_len = nullptr, *comp_cells = nullptr, *tcount = nullptr;
+    // reset path (pgx_reset.hip): unpadded u8 maps, per-env flags / generation counters, chunked scratch
+    uint8_t* map_u8 = nullptr;            // [B][H*W]
+    uint8_t *todo = nullptr, *regen = nullptr;  // [B]
+    uint32_t* epoch = nullptr;            // [B]
+    uint32_t* fail_count = nullptr;       // [1]
+    uint32_t *labels = nullptr, *pending = nullptr;  // [chunk_envs][H*W], allocated on first use
+    int chunk_envs = 0;
 };
 
 // ================================================================================================
@@ -149,6 +156,11 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
     alloc((void**)&e->active, BA);
     alloc((void**)&e->elapsed, B * sizeof(int32_t));
     alloc((void**)&e->macc, B * sizeof(int4));
+    alloc((void**)&e->map_u8, B * (size_t)cfg->height * cfg->width);
+    alloc((void**)&e->todo, B);
+    alloc((void**)&e->regen, B);
+    alloc((void**)&e->epoch, B * sizeof(uint32_t));
+    alloc((void**)&e->fail_count, sizeof(uint32_t));
     if (cfg->on_target == PGX_ON_TARGET_RESTART) {
         const size_t cells = B * (size_t)cfg->height * cfg->width;
         alloc((void**)&e->comp_begin, cells * sizeof(uint32_t));
@@ -180,7 +192,8 @@ int pgx_destroy(pgx_env* e) {
     if (!e) return PGX_OK;
     DeviceGuard guard(e->device);
     void* ptrs[] = {e->obst,   e->pos,     e->tgt,        e->pos0,     e->tgt0,       e->active,
-                    e->elapsed, e->comp_begin, e->comp_len, e->comp_cells, e->tcount, e->dbg, e->macc};
+                    e->elapsed, e->comp_begin, e->comp_len, e->comp_cells, e->tcount, e->dbg, e->macc,
+                    e->map_u8, e->todo, e->regen, e->epoch, e->fail_count, e->labels, e->pending};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete e;
@@ -197,50 +210,17 @@ int64_t pgx_agent_elems(const pgx_env* e) {
     return (int64_t)e->cfg.batch * e->cfg.num_agents;
 }
 
-// ---- connected components on the host (lifelong mode only; reset path, not the hot path) ----------
-static void label_components_host(const uint8_t* obst, int H, int Wd, uint32_t* comp_begin, uint32_t* comp_len,
-                                  uint32_t* comp_cells, std::vector<int32_t>& label, std::vector<int32_t>& stack) {
-    const int cells = H * Wd;
-    label.assign(cells, -1);
-    std::vector<uint32_t> count;
-    for (int s = 0; s < cells; ++s) {
-        if (obst[s] != 0 || label[s] >= 0) continue;
-        const int cid = (int)count.size();
-        count.push_back(0);
-        label[s] = cid;
-        stack.clear();
-        stack.push_back(s);
-        while (!stack.empty()) {
-            const int c = stack.back();
-            stack.pop_back();
-            count[cid]++;
-            const int x = c / Wd, y = c - x * Wd;
-            const int nb[4] = {x > 0 ? c - Wd : -1, x + 1 < H ? c + Wd : -1, y > 0 ? c - 1 : -1, y + 1 < Wd ? c + 1 : -1};
-            for (int k = 0; k < 4; ++k) {
-                const int n = nb[k];
-                if (n >= 0 && obst[n] == 0 && label[n] < 0) {
-                    label[n] = cid;
-                    stack.push_back(n);
-                }
-            }
-        }
-    }
-    std::vector<uint32_t> begin(count.size() + 1, 0);
-    for (size_t i = 0; i < count.size(); ++i) begin[i + 1] = begin[i] + count[i];
-    std::vector<uint32_t> fill(begin.begin(), begin.end() - 1);
-    for (int c = 0; c < cells; ++c) {
-        if (label[c] < 0) {
-            comp_begin[c] = 0;
-            comp_len[c] = 0;
-            continue;
-        }
-        const int cid = label[c];
-        comp_begin[c] = begin[cid];
-        comp_len[c] = count[cid];
-        const int x = c / Wd, y = c - x * Wd;
-        comp_cells[fill[cid]++] = ((uint32_t)x << 16) | (uint32_t)y;
-    }
-    for (uint32_t i = begin.back(); i < (uint32_t)cells; ++i) comp_cells[i] = 0;
+// ---- reset path ---------------------------------------------------------------------------------------
+// Scratch of the component labelling: two words per cell for a chunk of environments (<= 256 MiB in total).
+static int ensure_reset_scratch(pgx_env* e) {
+    if (e->labels) return PGX_OK;
+    const size_t cells = (size_t)e->cfg.height * e->cfg.width;
+    size_t chunk = ((size_t)1 << 25) / cells;
+    chunk = std::max<size_t>(1, std::min<size_t>(chunk, (size_t)e->cfg.batch));
+    PGX_HIP(hipMalloc((void**)&e->labels, chunk * cells * sizeof(uint32_t)));
+    PGX_HIP(hipMalloc((void**)&e->pending, chunk * cells * sizeof(uint32_t)));
+    e->chunk_envs = (int)chunk;
+    return PGX_OK;
 }
 
 int pgx_reset_from_state(pgx_env* e, const uint8_t* obstacles, const int32_t* agent_xy, const int32_t* target_xy,
@@ -251,35 +231,88 @@ int pgx_reset_from_state(pgx_env* e, const uint8_t* obstacles, const int32_t* ag
     hipStream_t s = (hipStream_t)stream;
     const pgx_config& c = e->cfg;
     const size_t B = (size_t)c.batch, BA = B * c.num_agents;
-    PGX_HIP(pgx::launch_pack_obstacles(obstacles, e->obst, c.batch, c.height, c.width, c.obs_radius, e->wpr, e->bmw, s));
+    const int cells = c.height * c.width;
+    PGX_HIP(hipMemcpyAsync(e->map_u8, obstacles, B * cells, hipMemcpyDeviceToDevice, s));
+    PGX_HIP(pgx::launch_reset_begin(nullptr, e->todo, e->regen, e->epoch, c.batch, s));
+    PGX_HIP(pgx::launch_pack_obstacles(e->map_u8, nullptr, e->obst, c.batch, c.height, c.width, c.obs_radius, e->wpr,
+                                       e->bmw, s));
     PGX_HIP(pgx::launch_pack_agents(agent_xy, target_xy, e->pos, e->tgt, e->pos0, e->tgt0, e->active, e->tcount, BA,
                                     c.obs_radius, s));
     PGX_HIP(pgx::launch_zero_i32(e->elapsed, B, s));
     PGX_HIP(pgx::launch_zero_i32(reinterpret_cast<int32_t*>(e->macc), B * 4, s));
-    if (c.on_target == PGX_ON_TARGET_RESTART) {
-        const size_t cells = (size_t)c.height * c.width;
-        std::vector<uint8_t> h_obst(B * cells);
-        PGX_HIP(hipMemcpyAsync(h_obst.data(), obstacles, B * cells, hipMemcpyDeviceToHost, s));
-        PGX_HIP(hipStreamSynchronize(s));
-        std::vector<uint32_t> h_begin(B * cells), h_len(B * cells), h_cells(B * cells);
-        unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 16u));
-        nt = (unsigned)std::min<size_t>(nt, B);
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < nt; ++t) {
-            pool.emplace_back([&, t]() {
-                std::vector<int32_t> label, stack;
-                for (size_t b = t; b < B; b += nt)
-                    label_components_host(h_obst.data() + b * cells, c.height, c.width, h_begin.data() + b * cells,
-                                          h_len.data() + b * cells, h_cells.data() + b * cells, label, stack);
-            });
+    if (c.on_target == PGX_ON_TARGET_RESTART) {  // component tables of PogemaLifeLong, built on the device
+        if (int rc = ensure_reset_scratch(e)) return rc;
+        for (int b0 = 0; b0 < c.batch; b0 += e->chunk_envs) {
+            const int n = std::min(e->chunk_envs, c.batch - b0);
+            PGX_HIP(pgx::launch_ccl(e->map_u8, e->labels, e->pending, e->regen, b0, n, c.height, c.width, 0, s));
+            PGX_HIP(pgx::launch_tables(e->map_u8, e->labels, e->pending, e->regen, e->comp_begin, e->comp_len,
+                                       e->comp_cells, b0, n, c.width, cells, 0, s));
         }
-        for (auto& th : pool) th.join();
-        PGX_HIP(hipMemcpyAsync(e->comp_begin, h_begin.data(), B * cells * 4, hipMemcpyHostToDevice, s));
-        PGX_HIP(hipMemcpyAsync(e->comp_len, h_len.data(), B * cells * 4, hipMemcpyHostToDevice, s));
-        PGX_HIP(hipMemcpyAsync(e->comp_cells, h_cells.data(), B * cells * 4, hipMemcpyHostToDevice, s));
-        PGX_HIP(hipStreamSynchronize(s));
     }
     e->has_state = true;
+    return PGX_OK;
+}
+
+int pgx_reset_random(pgx_env* e, float density, uint64_t seed, const uint8_t* shared_map, const uint8_t* env_mask,
+                     int32_t max_retries, void* stream) {
+    if (!e) return fail(PGX_E_INVALID, "pgx_reset_random: null handle");
+    if (!shared_map && !(density >= 0.0f && density <= 1.0f))
+        return fail(PGX_E_INVALID, "density %.3f outside [0, 1]", (double)density);
+    if (env_mask && !e->has_state) return fail(PGX_E_STATE, "masked pgx_reset_random before the first full reset");
+    const pgx_config& c = e->cfg;
+    const int cells = c.height * c.width;
+    if ((int64_t)2 * c.num_agents > (int64_t)cells)
+        return fail(PGX_E_PLACEMENT, "%d agents need %d distinct cells, map has %d", c.num_agents, 2 * c.num_agents, cells);
+    if (max_retries < 1) max_retries = 10;
+    DeviceGuard guard(e->device);
+    if (guard.err != hipSuccess) return fail(PGX_E_HIP, "cannot select device: %s", hipGetErrorString(guard.err));
+    if (int rc = ensure_reset_scratch(e)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t thr = pgx::gen_density_threshold(density);
+    const uint64_t key_base = seed + (uint64_t)c.env_index_base;  // env i draws instance (seed + global index)
+    const int shared = shared_map ? 1 : 0;
+    PGX_HIP(pgx::launch_reset_begin(env_mask, e->todo, e->regen, e->epoch, c.batch, s));
+    uint32_t failed_total = 0;
+    for (int b0 = 0; b0 < c.batch; b0 += e->chunk_envs) {
+        const int n = std::min(e->chunk_envs, c.batch - b0);
+        uint32_t failed = 0;
+        for (int attempt = 0; attempt < max_retries; ++attempt) {
+            PGX_HIP(hipMemsetAsync(e->fail_count, 0, sizeof(uint32_t), s));
+            if (!shared || attempt == 0)
+                PGX_HIP(pgx::launch_gen_obstacles(e->map_u8, shared_map, e->todo, e->epoch, b0, n, cells, thr, key_base,
+                                                  (uint32_t)attempt, s));
+            PGX_HIP(pgx::launch_ccl(shared ? shared_map : e->map_u8, e->labels, e->pending, e->todo, b0, n, c.height,
+                                    c.width, shared, s));
+            PGX_HIP(pgx::launch_place(e->map_u8, e->labels, e->pending, e->todo, e->epoch, e->pos, e->tgt, e->pos0,
+                                      e->tgt0, e->active, e->tcount, e->elapsed, e->macc, e->fail_count, b0, n,
+                                      c.num_agents, c.width, cells, c.obs_radius, shared, key_base, (uint32_t)attempt, s));
+            PGX_HIP(hipMemcpyAsync(&failed, e->fail_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            PGX_HIP(hipStreamSynchronize(s));  // reset path: the retry decision needs the failure count
+            if (failed == 0) break;
+        }
+        failed_total += failed;
+        if (c.on_target == PGX_ON_TARGET_RESTART && failed == 0)
+            PGX_HIP(pgx::launch_tables(e->map_u8, e->labels, e->pending, e->regen, e->comp_begin, e->comp_len,
+                                       e->comp_cells, b0, n, c.width, cells, shared, s));
+    }
+    if (failed_total) {
+        e->has_state = false;
+        return fail(PGX_E_PLACEMENT, "could not place %d agents in %u environment(s) after %d attempts (density %.2f, %dx%d)",
+                    c.num_agents, failed_total, max_retries, (double)density, c.height, c.width);
+    }
+    PGX_HIP(pgx::launch_pack_obstacles(e->map_u8, e->regen, e->obst, c.batch, c.height, c.width, c.obs_radius, e->wpr,
+                                       e->bmw, s));
+    e->has_state = true;
+    return PGX_OK;
+}
+
+int pgx_get_map(pgx_env* e, uint8_t* obstacles, void* stream) {
+    if (!e || !obstacles) return fail(PGX_E_INVALID, "pgx_get_map: null argument");
+    if (!e->has_state) return fail(PGX_E_STATE, "pgx_get_map called before a reset");
+    DeviceGuard guard(e->device);
+    if (guard.err != hipSuccess) return fail(PGX_E_HIP, "cannot select device: %s", hipGetErrorString(guard.err));
+    PGX_HIP(hipMemcpyAsync(obstacles, e->map_u8, (size_t)e->cfg.batch * e->cfg.height * e->cfg.width,
+                           hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return PGX_OK;
 }
 
@@ -396,95 +429,82 @@ int pgx_debug_timestamps(pgx_env* e, unsigned long long* host_out, int64_t max_e
 // ================================================================================================
 namespace {
 
-struct Xoshiro {
-    uint64_t s[4];
-    static uint64_t sm(uint64_t& z) {
-        z += 0x9E3779B97F4A7C15ull;
-        uint64_t x = z;
-        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-        x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-        return x ^ (x >> 31);
-    }
-    explicit Xoshiro(uint64_t seed) {
-        uint64_t z = seed;
-        for (auto& v : s) v = sm(z);
-    }
-    static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
-    uint64_t next() {
-        const uint64_t result = rotl(s[1] * 5, 7) * 9;
-        const uint64_t t = s[1] << 17;
-        s[2] ^= s[0];
-        s[3] ^= s[1];
-        s[1] ^= s[2];
-        s[0] ^= s[3];
-        s[2] ^= t;
-        s[3] = rotl(s[3], 45);
-        return result;
-    }
-    uint32_t below(uint32_t n) { return (uint32_t)(((next() >> 32) * (uint64_t)n) >> 32); }
-    float unit() { return (float)(next() >> 40) * (1.0f / 16777216.0f); }
+// ---- instance generator "GEN v2" (host side) ---------------------------------------------------------
+// Counter-based so that the device kernels (pgx_reset_random) draw the very same instances:
+//   h = mix(seed, global env, epoch, attempt);  obstacle(c) <=> hash(h, 'OBST', c) >> 40 < thr;
+//   candidates c_t = hash(h, 'PLAC', t) scaled to [0, cells); first visit of a component opens a pair,
+//   the next visit closes it.  Normative statement: oracle/generator_oracle.py (test infrastructure).
+inline uint64_t sm64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+struct GenScratch {
+    std::vector<int32_t> label, stack, pending;
+    std::vector<uint8_t> taken;
 };
 
-// one env; returns true when `A` start/target pairs were placed
-// (obst_out == nullptr: place on the given `obst` map instead of drawing one)
-bool generate_one(int H, int Wd, int A, float density, uint64_t seed, const uint8_t* obst_in, uint8_t* obst_out,
-                  int32_t* axy, int32_t* txy, std::vector<int32_t>& label, std::vector<int32_t>& stack,
-                  std::vector<int32_t>& order, std::vector<int32_t>& pending) {
-    Xoshiro rng(seed);
+void label_min_index(const uint8_t* obst, int H, int Wd, GenScratch& g) {
     const int cells = H * Wd;
-    if (obst_out)
-        for (int c = 0; c < cells; ++c) obst_out[c] = rng.unit() < density ? 1 : 0;
-    const uint8_t* obst = obst_out ? obst_out : obst_in;
-    // components
-    label.assign(cells, -1);
-    int ncomp = 0;
-    order.clear();
+    g.label.assign(cells, -1);
     for (int s = 0; s < cells; ++s) {
-        if (obst[s]) continue;
-        order.push_back(s);
-        if (label[s] >= 0) continue;
-        const int cid = ncomp++;
-        label[s] = cid;
-        stack.clear();
-        stack.push_back(s);
-        while (!stack.empty()) {
-            const int c = stack.back();
-            stack.pop_back();
+        if (obst[s] || g.label[s] >= 0) continue;
+        g.label[s] = s;  // row-major scan: the first cell reached is the component's smallest index
+        g.stack.clear();
+        g.stack.push_back(s);
+        while (!g.stack.empty()) {
+            const int c = g.stack.back();
+            g.stack.pop_back();
             const int x = c / Wd, y = c - x * Wd;
             const int nb[4] = {x > 0 ? c - Wd : -1, x + 1 < H ? c + Wd : -1, y > 0 ? c - 1 : -1, y + 1 < Wd ? c + 1 : -1};
             for (int k = 0; k < 4; ++k) {
                 const int n = nb[k];
-                if (n >= 0 && !obst[n] && label[n] < 0) {
-                    label[n] = cid;
-                    stack.push_back(n);
+                if (n >= 0 && !obst[n] && g.label[n] < 0) {
+                    g.label[n] = s;
+                    g.stack.push_back(n);
                 }
             }
         }
     }
-    // Fisher-Yates over the free cells
-    for (int i = (int)order.size() - 1; i > 0; --i) {
-        const int j = (int)rng.below((uint32_t)(i + 1));
-        std::swap(order[i], order[j]);
-    }
-    // pair cells inside one component: first visit opens a start, second visit closes it with a target
-    pending.assign(ncomp, -1);
+}
+
+// one env, one attempt; returns true when `A` start/target pairs were placed
+// (obst_out == nullptr: place on the given `obst_in` map instead of drawing one; labels then reused)
+bool generate_one(int H, int Wd, int A, uint32_t thr, uint64_t h, const uint8_t* obst_in, uint8_t* obst_out,
+                  bool relabel, int32_t* axy, int32_t* txy, GenScratch& g) {
+    const int cells = H * Wd;
+    if (obst_out)
+        for (int c = 0; c < cells; ++c)
+            obst_out[c] = (sm64(h ^ (pgx::GEN_TAG_OBST | (uint64_t)c)) >> 40) < thr ? 1 : 0;
+    const uint8_t* obst = obst_out ? obst_out : obst_in;
+    if (relabel) label_min_index(obst, H, Wd, g);
+    g.taken.assign(cells, 0);
+    g.pending.assign(cells, -1);
     int placed = 0;
-    for (size_t i = 0; i < order.size() && placed < A; ++i) {
-        const int c = order[i];
-        const int cid = label[c];
-        if (pending[cid] < 0) {
-            pending[cid] = c;
+    const uint32_t budget = pgx::gen_candidate_budget((uint32_t)cells);
+    for (uint32_t t = 0; t < budget && placed < A; ++t) {
+        const uint32_t c = (uint32_t)(((sm64(h ^ (pgx::GEN_TAG_PLACE | (uint64_t)t)) >> 32) * (uint64_t)cells) >> 32);
+        if (obst[c] || g.taken[c]) continue;
+        g.taken[c] = 1;
+        int32_t& open = g.pending[g.label[c]];
+        if (open < 0) {
+            open = (int32_t)c;
         } else {
-            const int s = pending[cid];
-            pending[cid] = -1;
-            axy[2 * placed] = s / Wd;
-            axy[2 * placed + 1] = s % Wd;
-            txy[2 * placed] = c / Wd;
-            txy[2 * placed + 1] = c % Wd;
+            axy[2 * placed] = open / Wd;
+            axy[2 * placed + 1] = open % Wd;
+            txy[2 * placed] = (int32_t)c / Wd;
+            txy[2 * placed + 1] = (int32_t)c % Wd;
+            open = -1;
             ++placed;
         }
     }
     return placed == A;
+}
+
+inline uint64_t instance_hash(uint64_t seed, uint64_t env, uint32_t epoch, uint32_t attempt) {
+    return sm64(sm64(sm64(seed) ^ env) ^ (((uint64_t)epoch << 32) | attempt));
 }
 
 }  // namespace
@@ -498,6 +518,7 @@ int pgx_generate(int32_t batch, int32_t height, int32_t width, int32_t num_agent
         return fail(PGX_E_PLACEMENT, "%d agents need %d distinct cells, map has %d", num_agents, 2 * num_agents,
                     height * width);
     if (max_retries < 1) max_retries = 10;
+    const uint32_t thr = pgx::gen_density_threshold(density);
     unsigned nt = nthreads > 0 ? (unsigned)nthreads : std::max(1u, std::thread::hardware_concurrency());
     nt = (unsigned)std::min<int64_t>(nt, batch);
     const size_t cells = (size_t)height * width;
@@ -505,15 +526,15 @@ int pgx_generate(int32_t batch, int32_t height, int32_t width, int32_t num_agent
     std::vector<std::thread> pool;
     for (unsigned t = 0; t < nt; ++t) {
         pool.emplace_back([&, t]() {
-            std::vector<int32_t> label, stack, order, pending;
+            GenScratch g;
             for (int64_t b = t; b < batch; b += nt) {
                 bool ok = false;
                 for (int attempt = 0; attempt < max_retries && !ok; ++attempt) {
-                    // env b, attempt k draws from stream (seed0 + b) advanced by k * 2^32
-                    const uint64_t seed = (seed0 + (uint64_t)b) ^ ((uint64_t)attempt << 40);
-                    ok = generate_one(height, width, num_agents, density, seed, nullptr, obstacles + b * cells,
-                                      agent_xy + (size_t)b * num_agents * 2, target_xy + (size_t)b * num_agents * 2,
-                                      label, stack, order, pending);
+                    // env b of a batch seeded seed0 is global env (seed0 + b) of stream 0, so shards and
+                    // single-env calls draw the same instances (seed + env_index_base + i in VecPogema)
+                    const uint64_t h = instance_hash(0, seed0 + (uint64_t)b, 0, (uint32_t)attempt);
+                    ok = generate_one(height, width, num_agents, thr, h, nullptr, obstacles + b * cells, true,
+                                      agent_xy + (size_t)b * num_agents * 2, target_xy + (size_t)b * num_agents * 2, g);
                 }
                 if (!ok && failed[t] < 0) failed[t] = (int)b;
             }
@@ -540,15 +561,14 @@ int pgx_place_agents(int32_t batch, int32_t height, int32_t width, int32_t num_a
     std::vector<std::thread> pool;
     for (unsigned t = 0; t < nt; ++t) {
         pool.emplace_back([&, t]() {
-            std::vector<int32_t> label, stack, order, pending;
+            GenScratch g;
             for (int64_t b = t; b < batch; b += nt) {
                 bool ok = false;
                 const uint8_t* m = obstacles + (shared_map ? 0 : b * cells);
                 for (int attempt = 0; attempt < max_retries && !ok; ++attempt) {
-                    const uint64_t seed = (seed0 + (uint64_t)b) ^ ((uint64_t)attempt << 40);
-                    ok = generate_one(height, width, num_agents, 0.0f, seed, m, nullptr,
-                                      agent_xy + (size_t)b * num_agents * 2, target_xy + (size_t)b * num_agents * 2,
-                                      label, stack, order, pending);
+                    const uint64_t h = instance_hash(0, seed0 + (uint64_t)b, 0, (uint32_t)attempt);
+                    ok = generate_one(height, width, num_agents, 0u, h, m, nullptr, attempt == 0 || !shared_map,
+                                      agent_xy + (size_t)b * num_agents * 2, target_xy + (size_t)b * num_agents * 2, g);
                 }
                 if (!ok && failed[t] < 0) failed[t] = (int)b;
             }

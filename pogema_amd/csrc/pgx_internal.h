@@ -10,6 +10,17 @@ enum { MODE_STEP = 0, MODE_OBSERVE = 1 };
 enum { COLLISION_PRIORITY = 0, COLLISION_BLOCK_BOTH = 1, COLLISION_SOFT = 2 };
 enum { ON_TARGET_FINISH = 0, ON_TARGET_RESTART = 1, ON_TARGET_NOTHING = 2 };
 
+// ---- instance generator "GEN v2" constants shared by the host generator and the device kernels ----
+constexpr uint64_t GEN_TAG_OBST = 0x4F42535400000000ull;   // 'OBST'
+constexpr uint64_t GEN_TAG_PLACE = 0x504C414300000000ull;  // 'PLAC'
+inline uint32_t gen_density_threshold(float density) {      // obstacle <=> 24 hash bits < thr
+    double t = (double)density * 16777216.0 + 0.5;
+    if (t < 0.0) t = 0.0;
+    if (t > 16777216.0) t = 16777216.0;
+    return (uint32_t)t;
+}
+__host__ __device__ inline uint32_t gen_candidate_budget(uint32_t cells) { return 32u * cells + 64u; }
+
 // Kernel argument block of the step kernel (passed by value: lands in SGPRs / kernarg segment).
 struct StepParams {
     // geometry
@@ -65,8 +76,26 @@ StepGeometry step_geometry(int batch, int A, int bmw, int W, bool allow_p16, int
 hipError_t prepare_step(const StepGeometry& g);
 hipError_t launch_step(const StepParams& p, const StepGeometry& g, hipStream_t stream);
 
-hipError_t launch_pack_obstacles(const uint8_t* obstacles, uint32_t* bm, int batch, int H, int Wd, int r,
-                                 int wpr, int bmw, hipStream_t stream);
+// `only` (device u8 [batch], may be null): pack just the flagged environments
+hipError_t launch_pack_obstacles(const uint8_t* obstacles, const uint8_t* only, uint32_t* bm, int batch, int H, int Wd,
+                                 int r, int wpr, int bmw, hipStream_t stream);
+
+// ---- on-device reset (pgx_reset.hip) ----------------------------------------------------------------
+hipError_t launch_reset_begin(const uint8_t* mask, uint8_t* todo, uint8_t* regen, uint32_t* epoch, int batch,
+                              hipStream_t s);
+hipError_t launch_gen_obstacles(uint8_t* obst, const uint8_t* shared_map, const uint8_t* todo, const uint32_t* epoch,
+                                int env_begin, int env_count, int cells, uint32_t thr, uint64_t key_base,
+                                uint32_t attempt, hipStream_t s);
+hipError_t launch_ccl(const uint8_t* obst, uint32_t* labels, uint32_t* pending, const uint8_t* todo, int env_begin,
+                      int env_count, int H, int Wd, int shared, hipStream_t s);
+hipError_t launch_place(const uint8_t* obst, const uint32_t* labels, uint32_t* pending, uint8_t* todo,
+                        const uint32_t* epoch, uint32_t* pos, uint32_t* tgt, uint32_t* pos0, uint32_t* tgt0,
+                        uint8_t* active, uint32_t* tcount, int32_t* elapsed, int4* macc, uint32_t* fail_count,
+                        int env_begin, int env_count, int A, int Wd, int cells, int r, int shared, uint64_t key_base,
+                        uint32_t attempt, hipStream_t s);
+hipError_t launch_tables(const uint8_t* obst, const uint32_t* labels, uint32_t* counters, const uint8_t* regen,
+                         uint32_t* comp_begin, uint32_t* comp_len, uint32_t* comp_cells, int env_begin, int env_count,
+                         int Wd, int cells, int shared, hipStream_t s);
 hipError_t launch_pack_agents(const int32_t* agent_xy, const int32_t* target_xy, uint32_t* pos, uint32_t* tgt,
                               uint32_t* pos0, uint32_t* tgt0, uint8_t* active, uint32_t* tcount, size_t n,
                               int r, hipStream_t stream);

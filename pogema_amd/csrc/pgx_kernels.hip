@@ -621,12 +621,13 @@ __global__ __launch_bounds__(MW ? 1024 : 64) void step_kernel(const StepParams p
 // ------------------------------------------------------------------------------------------------
 // u8 [B,H,W] obstacles -> padded 1-bit-per-cell bitmap with the artificial border of SURVEY A1:
 // padding r, OBSTACLE ring at offset r-1 (and at r+H / r+W), FREE outside.
-__global__ void pack_obstacles_kernel(const uint8_t* __restrict__ obstacles, uint32_t* __restrict__ bm,
-                                      int batch, int H, int Wd, int r, int wpr, int bmw) {
+__global__ void pack_obstacles_kernel(const uint8_t* __restrict__ obstacles, const uint8_t* __restrict__ only,
+                                      uint32_t* __restrict__ bm, int batch, int H, int Wd, int r, int wpr, int bmw) {
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)batch * bmw;
     if (gid >= total) return;
     const int env = (int)(gid / bmw);
+    if (only && !only[env]) return;
     const int w = (int)(gid - (size_t)env * bmw);
     const int x = w / wpr;
     const int y0 = (w - x * wpr) * 32;
@@ -769,12 +770,12 @@ hipError_t launch_step(const StepParams& p, const StepGeometry& g, hipStream_t s
     return hipLaunchKernel(fn, dim3(blocks), dim3(64 * g.waves), kargs, g.lds_bytes, stream);
 }
 
-hipError_t launch_pack_obstacles(const uint8_t* obstacles, uint32_t* bm, int batch, int H, int Wd, int r,
-                                 int wpr, int bmw, hipStream_t stream) {
+hipError_t launch_pack_obstacles(const uint8_t* obstacles, const uint8_t* only, uint32_t* bm, int batch, int H, int Wd,
+                                 int r, int wpr, int bmw, hipStream_t stream) {
     const size_t total = (size_t)batch * bmw;
     const int bs = 256;
     hipLaunchKernelGGL(pack_obstacles_kernel, dim3((unsigned)((total + bs - 1) / bs)), dim3(bs), 0, stream,
-                       obstacles, bm, batch, H, Wd, r, wpr, bmw);
+                       obstacles, only, bm, batch, H, Wd, r, wpr, bmw);
     return hipGetLastError();
 }
 

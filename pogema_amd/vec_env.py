@@ -104,11 +104,7 @@ class VecPogema:
         (obstacles u8 [B,H,W], agents_xy i32 [B,A,2], targets_xy i32 [B,A,2])."""
         gc = self.grid_config
         B, H, Wd, A = self.batch, self.height, self.width, self.num_agents
-        if seed is None:
-            seed = self._seed
-        if seed is None:
-            seed = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0] >> 1)
-        seed0 = (int(seed) + self.env_index_base) & 0xFFFFFFFFFFFFFFFF
+        seed0 = (self._resolve_seed(seed) + self.env_index_base) & 0xFFFFFFFFFFFFFFFF
         agents = np.empty((B, A, 2), dtype=np.int32)
         targets = np.empty((B, A, 2), dtype=np.int32)
         if gc.map is not None:
@@ -179,13 +175,73 @@ class VecPogema:
         self._initial = (d_obst, d_agents, d_targets)  # initial state; xy of POMAPF/MAPF views is relative to it
         return self._wrap_obs(self.observe())
 
+    def _resolve_seed(self, seed):
+        if seed is None:
+            seed = self._seed
+        if seed is None:
+            seed = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0] >> 1)
+        return int(seed) & 0xFFFFFFFFFFFFFFFF
+
+    def _shared_map_tensor(self):
+        gc = self.grid_config
+        if gc.map is None:
+            return None
+        one = np.ascontiguousarray(np.array(gc.map, dtype=np.uint8) != 0, dtype=np.uint8)
+        return torch.from_numpy(one).to(self.device)
+
+    def _refresh_initial(self):
+        """(obstacles u8 [B,H,W], agents_xy, targets_xy) of the state just installed, as device tensors."""
+        maps = torch.empty((self.batch, self.height, self.width), dtype=torch.uint8, device=self.device)
+        _lib.check(self._lib.pgx_get_map(self._handle, maps.data_ptr(), self._stream()))
+        st = self.get_state()
+        self._initial = (maps, st["agents_xy"], st["targets_xy"])
+
     def reset(self, seed: Optional[int] = None, options=None):
-        """gymnasium-style reset: draws fresh instances (env i uses seed + env_index_base + i) and
-        returns (obs, infos)."""
-        obstacles, agents, targets = self.generate(seed)
-        obs = self.reset_from_state(obstacles, agents, targets, validate=False)
+        """gymnasium-style reset: draws fresh instances ON THE DEVICE (env i draws instance
+        seed + env_index_base + i; `generate()` yields the same instances on the host) and returns (obs, infos).
+        With an explicit `map` AND `agents_xy`/`targets_xy` in the GridConfig nothing is random: that state is installed."""
+        gc = self.grid_config
+        if gc.map is not None and gc.agents_xy is not None:
+            obstacles, agents, targets = self.generate(seed)
+            obs = self.reset_from_state(obstacles, agents, targets, validate=False)
+        else:
+            if gc.agents_xy is not None:
+                raise NotImplementedError("agents_xy/targets_xy need an explicit `map`")
+            shared = self._shared_map_tensor()
+            _lib.check(self._lib.pgx_reset_random(self._handle, float(gc.density), self._resolve_seed(seed),
+                                                  shared.data_ptr() if shared is not None else None, None, 10,
+                                                  self._stream()))
+            self._reset_seed = self._resolve_seed(seed)
+            self._refresh_initial()
+            obs = self._wrap_obs(self.observe())
         infos = {"is_active": torch.ones((self.batch, self.num_agents), dtype=torch.bool, device=self.device)}
         return obs, infos
+
+    def reset_where(self, mask, seed: Optional[int] = None):
+        """New random instances for the envs flagged in `mask` (bool/uint8 [batch], e.g. infos['episode_done']):
+        the vectorised form of calling the reference's `reset()` on the finished environments only.  Each call
+        advances the flagged envs' generation counter, so they never see the same instance twice.  Returns
+        the full observation tensor (unflagged envs keep their state)."""
+        if not isinstance(mask, torch.Tensor):
+            mask = torch.as_tensor(np.asarray(mask))
+        mask = mask.to(self.device).to(torch.uint8).contiguous()
+        if mask.numel() != self.batch:
+            raise ValueError(f"mask must have {self.batch} entries")
+        gc = self.grid_config
+        if gc.map is not None and gc.agents_xy is not None:
+            raise NotImplementedError("reset_where draws random instances; this GridConfig fixes map and agents")
+        if seed is None:
+            seed = getattr(self, "_reset_seed", None)
+        shared = self._shared_map_tensor()
+        _lib.check(self._lib.pgx_reset_random(self._handle, float(gc.density), self._resolve_seed(seed),
+                                              shared.data_ptr() if shared is not None else None, mask.data_ptr(), 10,
+                                              self._stream()))
+        old = self._initial
+        self._refresh_initial()  # only the flagged envs have a new initial state
+        keep = mask == 0
+        self._initial = tuple(torch.where(keep.view(-1, *([1] * (new.dim() - 1))), o.to(new.dtype), new)
+                              for o, new in zip(old, self._initial))
+        return self._wrap_obs(self.observe())
 
     # ------------------------------------------------------------------------------------------
     def _alloc_outputs(self):

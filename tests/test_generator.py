@@ -70,3 +70,62 @@ def test_place_on_given_map(engine_lib):
     _lib.check(engine_lib.pgx_place_agents(8, 5, 7, 3, 42, 10, 2, m.ctypes.data, 1, a.ctypes.data, t.ctypes.data))
     assert ((a[..., 0] < 2) == (t[..., 0] < 2)).all(), "pairs stay on their side of the wall"
     assert (m[a[..., 0], a[..., 1]] == 0).all() and (m[t[..., 0], t[..., 1]] == 0).all()
+
+
+# ---- generator "GEN v2": normative Python statement == plain-C port == the product's host generator ----
+GEN_CASES = [(6, 8, 8, 2, 0.3, 11), (5, 16, 16, 8, 0.3, 3), (3, 9, 21, 30, 0.1, 77), (2, 32, 32, 16, 0.45, 5)]
+
+
+def _c_generate(B, H, W, A, density, key_base, given_map=None, epochs=None, max_retries=50):
+    from oracle.c_oracle import load
+    lib = load()
+    lib.po_generate.argtypes = [C.c_int32] * 4 + [C.c_float, C.c_uint64, C.c_int64, C.c_void_p, C.c_int32, C.c_int32,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.po_generate.restype = C.c_int
+    o = np.ascontiguousarray(given_map, np.uint8) if given_map is not None else np.empty((B, H, W), np.uint8)
+    a = np.empty((B, A, 2), np.int32)
+    t = np.empty((B, A, 2), np.int32)
+    ep = None if epochs is None else np.ascontiguousarray(epochs, np.uint32).ctypes.data
+    st = lib.po_generate(B, H, W, A, density, 0, key_base, ep, max_retries, int(given_map is not None), o.ctypes.data,
+                         a.ctypes.data, t.ctypes.data)
+    return st, o, a, t
+
+
+@pytest.mark.parametrize("case", GEN_CASES)
+def test_host_generator_equals_oracles(case):
+    from oracle import generator_oracle as G
+    B, H, W, A, density, seed = case
+    o, a, t = generate_instances(B, H, W, A, density, seed)
+    ro, ra, rt = G.generate_batch(0, B, H, W, A, density, env_index_base=seed, max_retries=50)
+    assert np.array_equal(o, ro) and np.array_equal(a, ra) and np.array_equal(t, rt)
+    st, co, ca, ct = _c_generate(B, H, W, A, density, seed)
+    assert st == 0 and np.array_equal(o, co) and np.array_equal(a, ca) and np.array_equal(t, ct)
+
+
+def test_generator_oracle_epochs_and_given_map():
+    from oracle import generator_oracle as G
+    m = np.zeros((5, 7), np.uint8)
+    m[2, :] = 1
+    for epoch in (0, 1, 5):
+        _, pa, pt = G.generate_instance(0, 42, 5, 7, 3, 0.0, epoch=epoch, given_map=m)
+        st, _, ca, ct = _c_generate(1, 5, 7, 3, 0.0, 42, given_map=m, epochs=[epoch])
+        assert st == 0 and np.array_equal(pa, ca[0]) and np.array_equal(pt, ct[0])
+    a0 = G.generate_instance(0, 42, 5, 7, 3, 0.0, epoch=0, given_map=m)[1]
+    a1 = G.generate_instance(0, 42, 5, 7, 3, 0.0, epoch=1, given_map=m)[1]
+    assert not np.array_equal(a0, a1), "a new generation draws a new placement"
+    with pytest.raises(OverflowError):
+        G.generate_instance(0, 0, 4, 4, 9, 0.0)
+    with pytest.raises(OverflowError):
+        G.generate_instance(0, 0, 4, 4, 4, 0.9, max_retries=3)
+
+
+def test_generator_labels_are_min_indices():
+    from oracle import generator_oracle as G
+    rng = np.random.default_rng(0)
+    obst = (rng.random((12, 15)) < 0.4).astype(np.uint8)
+    lab = G.min_index_labels(obst)
+    ref, pts = label_components(obst)
+    for comp in pts:
+        idx = [x * 15 + y for x, y in comp]
+        assert all(lab[x, y] == min(idx) for x, y in comp)
+    assert (lab[obst == 1] == -1).all()

@@ -149,7 +149,7 @@ __device__ __forceinline__ void lds_sync() {
 enum { MISC_FLAGS = 0, MISC_ARRIVED = 16, MISC_UNSOLVED = 17, MISC_OFFGOAL = 18, MISC_WORDS = 32 };
 
 template <int G, bool MW, bool P16>
-__global__ __launch_bounds__(MW ? 1024 : 64) void step_kernel(const StepParams p) {
+__global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const StepParams p) {
     static_assert(!MW || G == 64, "multi-wave environments use full waves");
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
 

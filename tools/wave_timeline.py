@@ -12,7 +12,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 from pogema_amd import GridConfig, VecPogema, _lib  # noqa: E402
 
-batch, size, agents, r = 8192, 64, 64, 5
+WL = {"cfg1": (1024, 16, 8, 5), "cfg2": (8192, 64, 64, 5), "cfg3": (8192, 32, 16, 5), "cfg4": (4096, 256, 256, 7)}
+batch, size, agents, r = WL[sys.argv[1] if len(sys.argv) > 1 else "cfg2"]
 env = VecPogema(GridConfig(size=size, num_agents=agents, obs_radius=r, density=0.3, seed=0, collision_system="soft"),
                 batch=batch, auto_reset=True, reuse_buffers=True)
 env.reset(seed=0)
@@ -22,8 +23,10 @@ for _ in range(5):
 torch.cuda.synchronize()
 lib = _lib.load()
 lib.pgx_debug_timestamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
-buf = np.zeros((batch, 4), dtype=np.uint64)
+buf = np.zeros((batch, 4), dtype=np.uint64)  # one record per workgroup (<= batch)
 _lib.check(lib.pgx_debug_timestamps(env._handle, buf.ctypes.data, buf.size))
+buf = buf[buf[:, 0] != 0]
+print(f"{len(buf)} workgroups")
 t = (buf.astype(np.int64) - int(buf[:, 0].min())) / 100.0  # us
 print("kernel span (first start -> last end): %.1f us" % t[:, 3].max())
 for name, col in (("start", 0), ("resolve done", 1), ("first store", 2), ("end", 3)):

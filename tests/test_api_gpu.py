@@ -103,3 +103,43 @@ def test_vec_metrics_tensor():
     assert ((m[:, 0] >= 0) & (m[:, 0] <= 1)).all() and ((m[:, 1] == 0) | (m[:, 1] == 1)).all()
     assert (m[:, 2] >= 1).all() and (m[:, 2] <= 5).all() and (m[:, 4] <= 5).all()
     env.close()
+
+
+def test_step_in_hip_graph():
+    """pgx_step is one kernel launch on the caller's stream (no allocation, attribute call or sync), so it can be
+    captured in a HIP graph and replayed: graph replays must equal eager stepping of a twin env."""
+    import torch
+    from pogema_amd import GridConfig, VecPogema
+    B, S, A = 64, 16, 8
+    gc = GridConfig(size=S, num_agents=A, obs_radius=5, density=0.3, seed=4, collision_system="soft",
+                    max_episode_steps=16)
+    eager = VecPogema(gc, batch=B, auto_reset=True)
+    graphed = VecPogema(gc, batch=B, auto_reset=True)
+    o0, _ = eager.reset(seed=4)
+    o1, _ = graphed.reset(seed=4)
+    assert torch.equal(o0, o1)
+    static_actions = torch.zeros((B, A), dtype=torch.int64, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):  # warm-up on a side stream, as torch's graph recipe asks
+        graphed.step(static_actions)
+    torch.cuda.current_stream().wait_stream(side)
+    eager.step(static_actions)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = graphed.step(static_actions)
+    # the capture itself executes nothing: both envs are still one step in
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    for t in range(40):
+        acts = torch.randint(0, 5, (B, A), generator=gen, device="cuda")
+        static_actions.copy_(acts)
+        g.replay()
+        ref = eager.step(acts)
+        for a, b in zip(out[:4], ref[:4]):
+            assert torch.equal(a, b), f"step {t}"
+        assert torch.equal(out[4]["is_active"], ref[4]["is_active"])
+    se, sg = eager.get_state(), graphed.get_state()
+    for k in se:
+        assert torch.equal(se[k], sg[k])
+    eager.close()
+    graphed.close()

@@ -22,7 +22,12 @@ GEOMETRIES = [
     ("full_wave", 3, 12, 12, 64, 5, 0.15, 20, 64),       # G=64 exactly (configs[2] lane layout)
     ("odd_agents", 4, 9, 13, 37, 4, 0.1, 20, 10),        # rectangular map, A not a power of two
     ("two_slots", 3, 18, 18, 100, 3, 0.1, 16, 8),         # K=2 (A > 64), ragged second slot
-    ("four_slots", 2, 27, 27, 256, 7, 0.1, 10, 6),       # K=4, configs[4] lane layout / radius
+    ("four_slots", 2, 27, 27, 256, 7, 0.1, 10, 6),       # 4 waves per env, configs[4] lane layout / radius
+    ("a65", 2, 16, 16, 65, 3, 0.1, 10, 6),               # 2 waves per env, the second almost empty
+    ("three_waves_wide", 2, 24, 24, 130, 8, 0.05, 8, 6),  # 3 waves per env + generic (32-bit row mask) path, W=17
+    ("wide_window", 3, 20, 20, 10, 9, 0.1, 12, 8),       # single wave, generic path, W=19
+    ("max_radius", 2, 12, 12, 5, 15, 0.1, 10, 8),        # PGX_MAX_OBS_RADIUS: W=31, window larger than the map
+    ("a1024", 1, 52, 52, 1024, 2, 0.05, 5, 4),           # PGX_MAX_AGENTS: 16 waves (1024 threads) per env
 ]
 
 

@@ -1,0 +1,107 @@
+"""CPU (no GPU): the closed-form collision rules the HIP kernel evaluates (pgx_kernels.hip phase 2: all-pairs
+okey/ckey sweep + pointer-doubling closure) restated in numpy-free Python and checked with hypothesis against the
+LITERAL algorithms of the oracle (sequential `priority`, dict-based `block_both`, dict/recursion `soft`) on random
+crowded scenarios.  This is the derivation DESIGN.md section 4 states, machine-checked on tens of thousands of cases;
+tests/test_parity_gpu.py then checks the kernel itself."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+from oracle.pogema_oracle import MOVES, PogemaOracle
+
+NOWHERE = ("nowhere",)
+NOTHING = ("nothing",)
+
+
+def closed_form_moves(obst_padded, cur, active, actions, collision):
+    """New padded cells per agent, following the kernel's rules (one 'lane' per agent)."""
+    n = len(cur)
+    mover = [active[i] and actions[i] != 0 for i in range(n)]
+    dest = [(cur[i][0] + MOVES[actions[i]][0], cur[i][1] + MOVES[actions[i]][1]) for i in range(n)]
+    blocked = [mover[i] and obst_padded[dest[i]] != 0 for i in range(n)]
+    vis = [cur[i] if active[i] else NOWHERE for i in range(n)]
+    claims = [(active[i] if collision == "block_both" else mover[i]) for i in range(n)]
+    want = [dest[i] if claims[i] else NOTHING for i in range(n)]
+    # the sweep: occupant of my destination, lower-index claimants of my destination
+    occ = [next((j for j in range(n) if j != i and vis[j] == want[i]), -1) for i in range(n)]
+    others = [[j for j in range(n) if j != i and want[j] == want[i]] for i in range(n)]
+    stay = [False] * n
+    nxt = [-1] * n
+    for i in range(n):
+        lower = [j for j in others[i] if j < i]
+        c1 = max(lower) if lower else -1
+        o = occ[i]
+        if collision == "block_both":
+            stay[i] = (not mover[i]) or blocked[i] or o >= 0 or len(others[i]) > 0
+            continue
+        nxt[i] = o if mover[i] else -1
+        if collision == "priority":
+            stay[i] = (not mover[i]) or blocked[i] or o > i or c1 > o
+        else:
+            stay[i] = (not mover[i]) or blocked[i] or bool(lower)
+            if nxt[i] >= 0 and want[nxt[i]] == cur[i]:
+                stay[i] = True  # edge swap
+    if collision != "block_both":
+        rounds = 1
+        while (1 << rounds) < n:
+            rounds += 1
+        for _ in range(rounds):  # pointer doubling, synchronous rounds like the kernel
+            if not any(nxt[i] >= 0 and not stay[i] for i in range(n)):
+                break
+            snap = [(stay[i], nxt[i]) for i in range(n)]
+            for i in range(n):
+                if nxt[i] >= 0:
+                    s, nn = snap[nxt[i]]
+                    stay[i] = stay[i] or s
+                    nxt[i] = nn
+    return [cur[i] if stay[i] else dest[i] for i in range(n)]
+
+
+@st.composite
+def scenarios(draw):
+    h = draw(st.integers(2, 6))
+    w = draw(st.integers(2, 6))
+    cells = [(x, y) for x in range(h) for y in range(w)]
+    n_obst = draw(st.integers(0, max(0, h * w // 4)))
+    perm = draw(st.permutations(cells))
+    obst_cells, free = perm[:n_obst], perm[n_obst:]
+    n = draw(st.integers(1, min(len(free), 12)))
+    starts = free[:n]
+    targets = [draw(st.sampled_from(free)) for _ in range(n)]
+    steps = draw(st.integers(1, 4))
+    actions = [[draw(st.integers(0, 4)) for _ in range(n)] for _ in range(steps)]
+    obstacles = np.zeros((h, w), np.uint8)
+    for c in obst_cells:
+        obstacles[c] = 1
+    return obstacles, starts, targets, actions
+
+
+@pytest.mark.parametrize("collision", ["priority", "block_both", "soft"])
+@pytest.mark.parametrize("on_target", ["finish", "nothing"])
+@settings(max_examples=1500, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large])
+@given(sc=scenarios())
+def test_closed_form_equals_literal_algorithm(collision, on_target, sc):
+    obstacles, starts, targets, actions = sc
+    env = PogemaOracle(obstacles, starts, targets, obs_radius=1, collision_system=collision, on_target=on_target,
+                       max_episode_steps=1000)
+    g = env.grid
+    for acts in actions:
+        cur = list(g.positions_xy)
+        active = [bool(g.is_active[i]) for i in range(len(cur))]
+        expect = closed_form_moves(g.obstacles, cur, active, acts, collision)
+        env.step(list(acts))
+        assert list(g.positions_xy) == expect, (collision, cur, active, acts)
+        # invariants every collision system keeps
+        vis = [p for i, p in enumerate(g.positions_xy) if g.is_active[i]]
+        assert len(set(vis)) == len(vis), "two visible agents share a cell"
+        assert all(g.obstacles[p] == 0 for p in g.positions_xy), "an agent stands on an obstacle"
+        assert all(abs(a[0] - b[0]) + abs(a[1] - b[1]) <= 1 for a, b in zip(cur, g.positions_xy))
+        occ = np.zeros_like(g.positions)
+        for p in vis:
+            occ[p] = 1
+        assert np.array_equal(occ, g.positions), "occupancy array == cells of the visible agents"
+        if collision != "priority":  # no edge swaps under block_both / soft
+            for i in range(len(cur)):
+                for j in range(i + 1, len(cur)):
+                    if active[i] and active[j] and cur[i] != cur[j]:
+                        assert not (g.positions_xy[i] == cur[j] and g.positions_xy[j] == cur[i])

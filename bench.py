@@ -90,8 +90,8 @@ def cpu_baseline(size, agents, r, collision, density, max_steps, target_seconds=
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--collision", default="soft", choices=["priority", "block_both", "soft"])
     ap.add_argument("--on-target", default="finish", choices=["finish", "restart", "nothing"])

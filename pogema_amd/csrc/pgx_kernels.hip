@@ -159,7 +159,14 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
     const int wave = MW ? (tid >> 6) : 0;
     const int nw = NT >> 6;
     const int epw = MW ? 1 : p.epw;
-    const int env0 = blockIdx.x * epw;
+    // Workgroup -> environment slice.  Hardware places workgroup b on XCD b % 8; with PGX_FLAGS bit 3 the slices of
+    // one XCD are contiguous in memory (each XCD's L2 then writes back one contiguous eighth of the tensor).
+    int blk = blockIdx.x;
+    if (p.flags & 8u) {
+        const int per_xcd = gridDim.x >> 3;
+        if (blk < (per_xcd << 3)) blk = (blk & 7) * per_xcd + (blk >> 3);
+    }
+    const int env0 = blk * epw;
     const int nenv = min(epw, p.batch - env0);
     const int A = p.num_agents;
     const int bmw = p.bm_words;
@@ -181,7 +188,7 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
     uint32_t* s_rows = s_misc + (MW ? MISC_WORDS : 0);  // generic path: [nag*3*W + 1] 32-bit row masks
 
     const bool dbg = (p.flags & 4u) && p.dbg;
-    if (dbg && tid == 0) p.dbg[(size_t)blockIdx.x * 4 + 0] = wall_clock64();
+    if (dbg && tid == 0) p.dbg[(size_t)blk * 4 + 0] = wall_clock64();
     // ---- phase 0: issue every global load of the step up front (one exposed HBM latency) ----------
     const int env_l = MW ? 0 : (lane / G);
     const int gbase = MW ? 0 : (lane & ~(G - 1));
@@ -427,7 +434,7 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
             }
         }
     }
-    if (dbg && tid == 0) p.dbg[(size_t)blockIdx.x * 4 + 1] = wall_clock64();
+    if (dbg && tid == 0) p.dbg[(size_t)blk * 4 + 1] = wall_clock64();
     if (!p.obs) return;
     lds_sync<MW>();
 
@@ -505,7 +512,7 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
                 out[e] = (float)((rows16[row] >> col) & 1u);
             }
         }
-        if (dbg && tid == 0) p.dbg[(size_t)blockIdx.x * 4 + 2] = wall_clock64();
+        if (dbg && tid == 0) p.dbg[(size_t)blk * 4 + 2] = wall_clock64();
         typedef float f32x4 __attribute__((ext_vector_type(4)));
         f32x4* out4 = reinterpret_cast<f32x4*>(out + head);
         const uint32_t* rows32 = smem;
@@ -534,7 +541,7 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
         }
         if (dbg && tid == 0) {
             __builtin_amdgcn_s_waitcnt(0);
-            p.dbg[(size_t)blockIdx.x * 4 + 3] = wall_clock64();
+            p.dbg[(size_t)blk * 4 + 3] = wall_clock64();
         }
         return;
     }
@@ -593,7 +600,7 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
                 out[e] = (float)((s_rows[row] >> col) & 1u);
             }
         }
-        if (dbg && tid == 0) p.dbg[(size_t)blockIdx.x * 4 + 2] = wall_clock64();
+        if (dbg && tid == 0) p.dbg[(size_t)blk * 4 + 2] = wall_clock64();
         typedef float f32x4 __attribute__((ext_vector_type(4)));
         f32x4* out4 = reinterpret_cast<f32x4*>(out + head);
         for (int q = tid; q < nvec; q += NT) {
@@ -611,7 +618,7 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
         }
         if (dbg && tid == 0) {
             __builtin_amdgcn_s_waitcnt(0);  // stores retired (vmcnt 0) before the end stamp
-            p.dbg[(size_t)blockIdx.x * 4 + 3] = wall_clock64();
+            p.dbg[(size_t)blk * 4 + 3] = wall_clock64();
         }
     }
 }

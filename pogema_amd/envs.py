@@ -104,6 +104,25 @@ class Pogema:
     def get_targets_xy(self):
         return [tuple(int(c) for c in p) for p in self._vec.get_state()["targets_xy"][0].cpu().numpy()]
 
+    def get_obstacles(self):
+        """Unpadded obstacle map (`Grid.get_obstacles(ignore_borders=True)`), int array [H, W]."""
+        return self._vec._initial[0][0].cpu().numpy().astype(np.int64)
+
+    def get_agents_xy_relative(self):
+        """Agent cells relative to their start cells (`Grid.get_agents_xy_relative`)."""
+        start = self._vec._initial[1][0].cpu().numpy()
+        return [(int(x - sx), int(y - sy)) for (x, y), (sx, sy) in zip(self.get_agents_xy(), start)]
+
+    def get_targets_xy_relative(self):
+        start = self._vec._initial[1][0].cpu().numpy()
+        return [(int(x - sx), int(y - sy)) for (x, y), (sx, sy) in zip(self.get_targets_xy(), start)]
+
+    def get_state(self):
+        """`Grid.get_state`-style export: obstacles, agents, targets, active flags (unpadded coordinates)."""
+        st = self._vec.get_state()
+        return {"obstacles": self.get_obstacles(), "agents_xy": self.get_agents_xy(), "targets_xy": self.get_targets_xy(),
+                "is_active": [bool(v) for v in st["is_active"][0].cpu().numpy()], "elapsed": int(st["elapsed"][0])}
+
     def close(self):
         self._vec.close()
 

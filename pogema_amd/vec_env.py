@@ -43,6 +43,10 @@ class VecPogema:
         self.observation_type = gc.observation_type  # 'default' tensor, or 'POMAPF' / 'MAPF' dict views
         if not gc.empty_outside:
             raise NotImplementedError("empty_outside=False draws from the reference's RNG; not implemented")
+        if gc.possible_agents_xy is not None or gc.possible_targets_xy is not None:
+            raise NotImplementedError("possible_agents_xy / possible_targets_xy are not supported by the engine's generator")
+        if gc.persistent:
+            raise NotImplementedError("persistent=True (PersistentWrapper / step_back) is outside the hot-path scope")
         if not torch.cuda.is_available():
             raise RuntimeError("pogema_amd needs a HIP device (torch.cuda.is_available() is False); "
                                "there is no CPU fallback")

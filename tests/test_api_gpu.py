@@ -143,3 +143,27 @@ def test_step_in_hip_graph():
         assert torch.equal(se[k], sg[k])
     eager.close()
     graphed.close()
+
+
+def test_list_api_state_accessors():
+    """`Grid`-style accessors of the single-env view after a seeded device reset and a few steps."""
+    from oracle import generator_oracle as G
+    from pogema_amd import GridConfig, pogema_v0
+    gc = GridConfig(size=10, num_agents=4, obs_radius=2, density=0.2, seed=13, collision_system="priority")
+    env = pogema_v0(gc)
+    env.reset(seed=13)
+    ro, ra, rt = G.generate_instance(0, 13, 10, 10, 4, 0.2)
+    assert np.array_equal(env.get_obstacles(), ro)
+    assert env.get_agents_xy() == [tuple(p) for p in ra.tolist()] and env.get_targets_xy() == [tuple(p) for p in rt.tolist()]
+    ref = PogemaOracle(ro, ra, rt, obs_radius=2, collision_system="priority", max_episode_steps=64)
+    for acts in ([1, 2, 3, 4], [4, 4, 0, 1], [2, 2, 2, 2]):
+        env.step(acts)
+        ref.step(acts)
+    st = ref.get_state()
+    assert env.get_agents_xy() == [tuple(p) for p in st["agents_xy"].tolist()]
+    rel = [(int(x - sx), int(y - sy)) for (x, y), (sx, sy) in zip(st["agents_xy"], ra)]
+    assert env.get_agents_xy_relative() == rel
+    full = env.get_state()
+    assert full["elapsed"] == 3 and full["is_active"] == [bool(v) for v in st["is_active"]]
+    assert env.get_targets_xy_relative() == [(int(x - sx), int(y - sy)) for (x, y), (sx, sy) in zip(rt, ra)]
+    env.close()

@@ -1,0 +1,43 @@
+"""Diagnostic: in-process, interleaved A/B of engine tuning knobs (PGX_FLAGS / PGX_EPW are read at pgx_create),
+so that box-to-box and warm-up drift cancel.  usage: python tools/ab_inproc.py cfg2 "PGX_FLAGS=0" "PGX_FLAGS=8" """
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from pogema_amd import GridConfig, VecPogema  # noqa: E402
+
+WL = {"cfg1": (1024, 16, 8, 5), "cfg2": (8192, 64, 64, 5), "cfg3": (8192, 32, 16, 5), "cfg4": (4096, 256, 256, 7)}
+wl = sys.argv[1]
+variants = sys.argv[2:]
+batch, size, agents, r = WL[wl]
+envs = []
+for v in variants:
+    for k in ("PGX_FLAGS", "PGX_EPW"):
+        os.environ.pop(k, None)
+    for kv in v.split(","):
+        if kv:
+            k, val = kv.split("=")
+            os.environ[k] = val
+    env = VecPogema(GridConfig(size=size, num_agents=agents, obs_radius=r, density=0.3, seed=0, collision_system="soft"),
+                    batch=batch, auto_reset=True, reuse_buffers=True)
+    env.reset(seed=0)
+    envs.append(env)
+acts = [torch.randint(0, 5, (batch, agents), device="cuda") for _ in range(8)]
+rounds, steps = 12, 60
+times = np.zeros((len(envs), rounds))
+for rd in range(rounds):
+    for i, env in enumerate(envs):
+        for k in range(5):
+            env.step(acts[k % 8])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for k in range(steps):
+            env.step(acts[k % 8])
+        e1.record()
+        torch.cuda.synchronize()
+        times[i, rd] = e0.elapsed_time(e1) / steps * 1e3
+for v, t in zip(variants, times):
+    print(f"{wl} {v:24s} median {np.median(t):8.2f} us  min {t.min():8.2f}  max {t.max():8.2f}")

@@ -34,10 +34,11 @@ WORKLOADS = {
 }
 
 
-def algorithmic_bytes_per_agent_step(size: int, agents: int, r: int) -> float:
-    """12*W^2 obs + 3*ceil(P^2/8)/A bitmaps + 21 bytes of per-agent state/IO."""
+def algorithmic_bytes_per_agent_step(size: int, agents: int, r: int, obs_bytes: int = 4) -> float:
+    """12*W^2 obs + 3*ceil(P^2/8)/A bitmaps + 21 bytes of per-agent state/IO
+    (3 * obs_bytes * W^2 for the observation when the non-drop-in uint8 mode is benchmarked)."""
     W, P = 2 * r + 1, size + 2 * r
-    return 12.0 * W * W + 3.0 * ((P * P + 7) // 8) / agents + 21.0
+    return 3.0 * obs_bytes * W * W + 3.0 * ((P * P + 7) // 8) / agents + 21.0
 
 
 def cpu_baseline(size, agents, r, collision, density, max_steps, target_seconds=12.0):
@@ -99,6 +100,8 @@ def main():
     ap.add_argument("--density", type=float, default=0.3)
     ap.add_argument("--max-episode-steps", type=int, default=64)
     ap.add_argument("--action-dtype", default="int64", choices=["int8", "int32", "int64"])
+    ap.add_argument("--obs-dtype", default="float32", choices=["float32", "uint8"],
+                    help="float32 = the reference's dtype (the headline); uint8 = the engine's lighter non-drop-in mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-obs", action="store_true", help="diagnostic: skip the observation write")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -128,7 +131,8 @@ def main():
     gc = GridConfig(size=size, density=args.density, num_agents=agents, obs_radius=r, seed=0,
                     collision_system=args.collision, on_target=args.on_target,
                     max_episode_steps=args.max_episode_steps)
-    env = VecPogema(gc, batch=batch, device=device, env_index_base=rank * batch, auto_reset=True, reuse_buffers=True)
+    env = VecPogema(gc, batch=batch, device=device, env_index_base=rank * batch, auto_reset=True, reuse_buffers=True,
+                    obs_dtype=torch.float32 if args.obs_dtype == "float32" else torch.uint8)
     env.reset(seed=0)
     tdt = {"int8": torch.int8, "int32": torch.int32, "int64": torch.int64}[args.action_dtype]
     gen = torch.Generator(device=device)
@@ -164,7 +168,7 @@ def main():
     if rank == 0:
         n_agent_steps = world * batch * agents * args.steps
         value = n_agent_steps / elapsed
-        bpas = algorithmic_bytes_per_agent_step(size, agents, r)
+        bpas = algorithmic_bytes_per_agent_step(size, agents, r, 4 if args.obs_dtype == "float32" else 1)
         alg_bytes = bpas * batch * agents  # per launch (one GPU)
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None
@@ -172,19 +176,21 @@ def main():
         if os.path.exists(pmc):
             try:
                 with open(pmc) as f:
-                    traffic = json.load(f).get(f"{args.workload}/{args.collision}", {}).get("hbm_bytes_per_launch")
+                    key = f"{args.workload}/{args.collision}" + ("" if args.obs_dtype == "float32" else "/uint8")
+                    traffic = json.load(f).get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         line = {
-            "metric": "agent-steps/sec (whole node), 64-agent 64x64 grid, batch=8192 envs" if args.workload == "cfg2"
-                      else f"agent-steps/sec (whole node), workload {args.workload}",
+            "metric": "agent-steps/sec (whole node), 64-agent 64x64 grid, batch=8192 envs"
+                      if (args.workload == "cfg2" and args.obs_dtype == "float32")
+                      else f"agent-steps/sec (whole node), workload {args.workload}, obs {args.obs_dtype}",
             "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[{args.workload[-1]}]: {batch} envs/GPU, {size}x{size} map, "
                                    f"{agents} agents, obs_radius {r}, density {args.density}",
                        "collision_system": args.collision, "on_target": args.on_target, "auto_reset": True,
-                       "max_episode_steps": args.max_episode_steps, "obs_dtype": "float32",
+                       "max_episode_steps": args.max_episode_steps, "obs_dtype": args.obs_dtype,
                        "action_dtype": args.action_dtype, "envs_per_gpu": batch, "sharding": f"batch-sharded x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

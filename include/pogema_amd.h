@@ -55,6 +55,12 @@ extern "C" {
 #define PGX_ACTION_I32 1
 #define PGX_ACTION_I64 2
 
+/* dtype of the observation buffer (pgx_config.obs_dtype).  F32 is the reference's dtype (gymnasium Box float32) and
+ * the drop-in default; U8 writes the same 0/1 planes one byte per cell -- a 4x lighter, non-drop-in mode for callers
+ * that cast on their side. */
+#define PGX_OBS_F32 0
+#define PGX_OBS_U8 1
+
 /* hard limits of this build */
 #define PGX_MAX_OBS_RADIUS 15   /* window side 2r+1 <= 31 (one 32-bit row mask per window row) */
 #define PGX_MAX_AGENTS 1024
@@ -72,7 +78,7 @@ typedef struct pgx_config {
     int32_t max_episode_steps; /* MultiTimeLimit; <= 0 disables truncation        */
     int32_t auto_reset;        /* 1: an env whose agents are all terminated or truncated is   */
                                /*    reset to its stored initial state inside the same step    */
-    int32_t reserved0;
+    int32_t obs_dtype;         /* PGX_OBS_* (0 = float32, the reference's dtype)                 */
     uint64_t seed;             /* lifelong (restart) target stream seed                        */
     int64_t env_index_base;    /* global index of env 0 of this shard (keeps lifelong streams  */
                                /* independent of how the batch is sharded over devices)        */
@@ -90,7 +96,7 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out);
 int pgx_destroy(pgx_env* env);
 
 /* Sizes of the caller-owned output buffers, in elements. */
-int64_t pgx_obs_elems(const pgx_env* env);   /* batch * agents * 3 * (2r+1)^2   (float32) */
+int64_t pgx_obs_elems(const pgx_env* env);   /* batch * agents * 3 * (2r+1)^2   (obs_dtype elements) */
 int64_t pgx_agent_elems(const pgx_env* env); /* batch * agents                            */
 
 /* ---- reset -------------------------------------------------------------------------------------- */
@@ -132,12 +138,13 @@ int pgx_get_map(pgx_env* env, uint8_t* obstacles, void* stream);
  * `MultiTimeLimit.step` (upstream pogema/envs.py, pogema/grid.py,
  * pogema/wrappers/multi_time_limit.py).
  *   actions      device [batch, agents] of action_dtype, values 0..4 (noop, up, down, left, right)
- *   obs          device f32 [batch, agents, 3, 2r+1, 2r+1]  (obstacles, agents, target)   may be NULL
+ *   obs          device f32 (or u8 when obs_dtype = PGX_OBS_U8) [batch, agents, 3, 2r+1, 2r+1]
+ *                (obstacles, agents, target)                                               may be NULL
  *   rewards      device f32 [batch, agents]
  *   terminated   device u8  [batch, agents]
  *   truncated    device u8  [batch, agents]
  *   is_active    device u8  [batch, agents]   infos[i]['is_active'] after the step      may be NULL */
-int pgx_step(pgx_env* env, const void* actions, int action_dtype, float* obs, float* rewards,
+int pgx_step(pgx_env* env, const void* actions, int action_dtype, void* obs, float* rewards,
              uint8_t* terminated, uint8_t* truncated, uint8_t* is_active, void* stream);
 
 /* Episode metrics, fused into pgx_step.  Replaces the metric wrappers of upstream pogema/wrappers/metrics.py
@@ -152,7 +159,7 @@ int pgx_set_metrics_buffers(pgx_env* env, float* metrics, uint8_t* episode_done)
 
 /* Observation of the current state without stepping.  Replaces `PogemaBase._obs()` as called by
  * `reset()`. */
-int pgx_observe(pgx_env* env, float* obs, void* stream);
+int pgx_observe(pgx_env* env, void* obs, void* stream);
 
 /* ---- state export ------------------------------------------------------------------------------- */
 /* Replaces `Grid.get_agents_xy` / `get_targets_xy` / `is_active` / the occupancy array (`positions`).

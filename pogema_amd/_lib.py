@@ -17,6 +17,28 @@ PGX_ABI_VERSION = 1
 COLLISION_SYSTEMS = {"priority": 0, "block_both": 1, "soft": 2}
 ON_TARGET = {"finish": 0, "restart": 1, "nothing": 2}
 ACTION_DTYPES = {"int8": 0, "int32": 1, "int64": 2}
+def _obs_dtypes():
+    import torch
+    return {torch.float32: 0, torch.uint8: 1}
+
+
+class _LazyObsDtypes(dict):
+    """torch dtype -> PGX_OBS_* code; built on first use so that importing this module stays cheap."""
+
+    def _fill(self):
+        if not dict.__len__(self):
+            self.update(_obs_dtypes())
+
+    def __contains__(self, k):
+        self._fill()
+        return dict.__contains__(self, k)
+
+    def __getitem__(self, k):
+        self._fill()
+        return dict.__getitem__(self, k)
+
+
+OBS_DTYPES = _LazyObsDtypes()
 METRIC_NAMES = ("ISR", "CSR", "ep_length", "SoC", "makespan", "avg_throughput")
 
 # every symbol include/pogema_amd.h declares; tests/test_abi.py checks the library exports them all
@@ -36,7 +58,7 @@ class PgxConfig(C.Structure):
     _fields_ = [
         ("batch", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("num_agents", C.c_int32),
         ("obs_radius", C.c_int32), ("collision_system", C.c_int32), ("on_target", C.c_int32),
-        ("max_episode_steps", C.c_int32), ("auto_reset", C.c_int32), ("reserved0", C.c_int32),
+        ("max_episode_steps", C.c_int32), ("auto_reset", C.c_int32), ("obs_dtype", C.c_int32),
         ("seed", C.c_uint64), ("env_index_base", C.c_int64),
     ]
 

@@ -111,6 +111,8 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
     if (cfg->collision_system < 0 || cfg->collision_system > 2)
         return fail(PGX_E_INVALID, "unknown collision_system %d", cfg->collision_system);
     if (cfg->on_target < 0 || cfg->on_target > 2) return fail(PGX_E_INVALID, "unknown on_target %d", cfg->on_target);
+    if (cfg->obs_dtype != PGX_OBS_F32 && cfg->obs_dtype != PGX_OBS_U8)
+        return fail(PGX_E_INVALID, "unknown obs_dtype %d", cfg->obs_dtype);
     if ((int64_t)cfg->num_agents > (int64_t)cfg->height * cfg->width)
         return fail(PGX_E_INVALID, "more agents than cells");
 
@@ -333,6 +335,7 @@ static void fill_params(const pgx_env* e, pgx::StepParams& p) {
     p.auto_reset = c.auto_reset;
     p.flags = e->flags;
     p.epw = e->geo.epw;
+    p.obs_u8 = e->cfg.obs_dtype == PGX_OBS_U8 ? 1 : 0;
     p.seed = c.seed;
     p.env_index_base = c.env_index_base;
     p.obst = e->obst;
@@ -352,7 +355,7 @@ static void fill_params(const pgx_env* e, pgx::StepParams& p) {
     p.episode_done = e->episode_done;
 }
 
-int pgx_step(pgx_env* e, const void* actions, int action_dtype, float* obs, float* rewards, uint8_t* terminated,
+int pgx_step(pgx_env* e, const void* actions, int action_dtype, void* obs, float* rewards, uint8_t* terminated,
              uint8_t* truncated, uint8_t* is_active, void* stream) {
     if (!e || !actions || !rewards || !terminated || !truncated) return fail(PGX_E_INVALID, "pgx_step: null argument");
     if (action_dtype < 0 || action_dtype > 2) return fail(PGX_E_INVALID, "pgx_step: bad action_dtype %d", action_dtype);
@@ -364,7 +367,7 @@ int pgx_step(pgx_env* e, const void* actions, int action_dtype, float* obs, floa
     p.mode = pgx::MODE_STEP;
     p.action_dtype = action_dtype;
     p.actions = actions;
-    p.obs = obs;
+    p.obs = static_cast<float*>(obs);
     p.rewards = rewards;
     p.terminated = terminated;
     p.truncated = truncated;
@@ -380,7 +383,7 @@ int pgx_set_metrics_buffers(pgx_env* e, float* metrics, uint8_t* episode_done) {
     return PGX_OK;
 }
 
-int pgx_observe(pgx_env* e, float* obs, void* stream) {
+int pgx_observe(pgx_env* e, void* obs, void* stream) {
     if (!e || !obs) return fail(PGX_E_INVALID, "pgx_observe: null argument");
     if (!e->has_state) return fail(PGX_E_STATE, "pgx_observe called before pgx_reset_from_state");
     DeviceGuard guard(e->device);
@@ -388,7 +391,7 @@ int pgx_observe(pgx_env* e, float* obs, void* stream) {
     pgx::StepParams p;
     fill_params(e, p);
     p.mode = pgx::MODE_OBSERVE;
-    p.obs = obs;
+    p.obs = static_cast<float*>(obs);
     PGX_HIP(pgx::launch_step(p, e->geo, (hipStream_t)stream));
     return PGX_OK;
 }

@@ -33,6 +33,7 @@ struct StepParams {
     // behaviour
     int32_t mode, collision, on_target, max_steps, auto_reset, action_dtype;
     int32_t epw;       // environments per wave (single-wave blocks, num_agents <= 64)
+    int32_t obs_u8;    // 1: `obs` is uint8 (one byte per cell) instead of float32
     uint32_t flags;    // tuning switches (PGX_FLAGS env var at pgx_create): bit0 = nontemporal obs stores
     uint64_t seed;
     int64_t env_index_base;

@@ -134,6 +134,44 @@ __device__ __forceinline__ void lds_sync() {
     }
 }
 
+// uint8 observation stream (obs_dtype = PGX_OBS_U8; NOT the drop-in dtype -- a 4x lighter mode for callers that
+// cast on their side): the workgroup's n cells as one byte each, 16 per lane per store.  `row_bits(row)` returns
+// the W-bit mask of flat window row `row` (rows past the end read as 0).  16 consecutive cells starting inside row
+// `row` at column `col` are funnelled out of ceil(16/W)+1 row masks and spread 4 bits -> 4 bytes with one multiply
+// ((x * 0x204081) & 0x01010101: bit i lands on bit 8i, no two partial products share a bit).
+template <typename RowBits>
+__device__ __forceinline__ void stream_obs_u8(uint8_t* out, size_t base, int n, int W, uint32_t magic, int tid, int NT,
+                                              bool nontemporal, RowBits row_bits) {
+    uint8_t* o = out + base;
+    const int head = min(n, (int)((16 - (base & 15)) & 15));
+    const int nvec = (n - head) >> 4;
+    const int tail0 = head + (nvec << 4);
+    if (tid < 32) {  // unaligned head / tail bytes
+        const int e = (tid < 16) ? tid : tail0 + (tid - 16);
+        const bool mine = (tid < 16) ? (tid < head) : (e < n);
+        if (mine) {
+            const int row = (int)__umulhi((uint32_t)e, magic);
+            o[e] = (uint8_t)((row_bits(row) >> (e - row * W)) & 1u);
+        }
+    }
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4* out4 = reinterpret_cast<u32x4*>(o + head);
+    for (int q = tid; q < nvec; q += NT) {
+        const int e0 = head + (q << 4);
+        int row = (int)__umulhi((uint32_t)e0, magic);
+        const int col = e0 - row * W;
+        uint32_t m = row_bits(row) >> col;
+        for (int have = W - col; have < 16; have += W) m |= row_bits(++row) << have;
+        u32x4 v;
+        v.x = ((m & 15u) * 0x204081u) & 0x01010101u;
+        v.y = (((m >> 4) & 15u) * 0x204081u) & 0x01010101u;
+        v.z = (((m >> 8) & 15u) * 0x204081u) & 0x01010101u;
+        v.w = (((m >> 12) & 15u) * 0x204081u) & 0x01010101u;
+        if (nontemporal) __builtin_nontemporal_store(v, &out4[q]);
+        else out4[q] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // The step kernel.  One lane = one agent, always.
 //   MW == false : block = 1 wave holding p.epw (<= 64/G) environments of G lanes each (G = next
@@ -495,9 +533,20 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
         if (tid < 4) rows16[nag * 3 * W + tid] = 0;
         lds_sync<MW>();
 
-        // ---- phase 4 (P16): stream the float32 observations ----------------------------------------------
+        // ---- phase 4 (P16): stream the observations --------------------------------------------------------
         const int n = nag * 3 * W * W;
         const size_t base = (size_t)env0 * A * 3 * W * W;
+        if (p.obs_u8) {
+            if (dbg && tid == 0) p.dbg[(size_t)blk * 4 + 2] = wall_clock64();
+            const int nrows = nag * 3 * W;
+            stream_obs_u8(reinterpret_cast<uint8_t*>(p.obs), base, n, W, p.w_magic, tid, NT, (p.flags & 1u) != 0,
+                          [&](int row) -> uint32_t { return row < nrows ? (uint32_t)rows16[row] : 0u; });
+            if (dbg && tid == 0) {
+                __builtin_amdgcn_s_waitcnt(0);
+                p.dbg[(size_t)blk * 4 + 3] = wall_clock64();
+            }
+            return;
+        }
         float* out = p.obs + base;
         const int head = min(n, (int)((4 - (base & 3)) & 3));
         const uint32_t magic = p.w_magic;
@@ -581,7 +630,13 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
     }
     lds_sync<MW>();
 
-    // ---- phase 4: stream the float32 observations, 16 bytes per lane per store ---------------------
+    // ---- phase 4: stream the observations, 16 bytes per lane per store ---------------------------------
+    if (p.obs_u8) {
+        const int nrows = nag * 3 * W;
+        stream_obs_u8(reinterpret_cast<uint8_t*>(p.obs), (size_t)env0 * A * 3 * W * W, nrows * W, W, p.w_magic, tid, NT,
+                      (p.flags & 1u) != 0, [&](int row) -> uint32_t { return row < nrows ? s_rows[row] : 0u; });
+        return;
+    }
     {
         const int n = nag * 3 * W * W;  // floats written by this workgroup
         const size_t base = (size_t)env0 * A * 3 * W * W;

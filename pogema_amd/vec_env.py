@@ -37,7 +37,8 @@ class VecPogema:
     """
 
     def __init__(self, grid_config: Optional[GridConfig] = None, batch: int = 1, device="cuda:0",
-                 env_index_base: int = 0, auto_reset: Optional[bool] = None, reuse_buffers: bool = False):
+                 env_index_base: int = 0, auto_reset: Optional[bool] = None, reuse_buffers: bool = False,
+                 obs_dtype=torch.float32):
         self.grid_config = grid_config if grid_config is not None else GridConfig(num_agents=2)
         gc = self.grid_config
         self.observation_type = gc.observation_type  # 'default' tensor, or 'POMAPF' / 'MAPF' dict views
@@ -63,12 +64,17 @@ class VecPogema:
             auto_reset = bool(gc.auto_reset) if gc.auto_reset is not None else False
         self.auto_reset = bool(auto_reset)
         self.reuse_buffers = bool(reuse_buffers)
+        # float32 is the reference's observation dtype (gymnasium Box float32) and the default; torch.uint8 writes
+        # the same 0/1 planes one byte per cell (4x fewer HBM bytes per step) for callers that cast on their side
+        if obs_dtype not in _lib.OBS_DTYPES:
+            raise ValueError(f"obs_dtype must be torch.float32 or torch.uint8, got {obs_dtype}")
+        self.obs_dtype = obs_dtype
         self._seed = gc.seed
         cfg = _lib.PgxConfig(
             batch=self.batch, height=self.height, width=self.width, num_agents=self.num_agents,
             obs_radius=self.obs_radius, collision_system=_lib.COLLISION_SYSTEMS[gc.collision_system],
             on_target=_lib.ON_TARGET[gc.on_target], max_episode_steps=int(gc.max_episode_steps),
-            auto_reset=int(self.auto_reset), reserved0=0, seed=int(gc.seed or 0),
+            auto_reset=int(self.auto_reset), obs_dtype=_lib.OBS_DTYPES[self.obs_dtype], seed=int(gc.seed or 0),
             env_index_base=self.env_index_base)
         self._handle = C.c_void_p()
         _lib.check(self._lib.pgx_create(C.byref(cfg), self.device_index, C.byref(self._handle)))
@@ -251,7 +257,7 @@ class VecPogema:
     def _alloc_outputs(self):
         B, A = self.batch, self.num_agents
         dev = self.device
-        return (torch.empty(self.obs_shape, dtype=torch.float32, device=dev),
+        return (torch.empty(self.obs_shape, dtype=self.obs_dtype, device=dev),
                 torch.empty((B, A), dtype=torch.float32, device=dev),
                 torch.empty((B, A), dtype=torch.bool, device=dev),
                 torch.empty((B, A), dtype=torch.bool, device=dev),
@@ -266,7 +272,9 @@ class VecPogema:
         return self._bufs[self._buf_i]
 
     def observe(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        obs = out if out is not None else torch.empty(self.obs_shape, dtype=torch.float32, device=self.device)
+        obs = out if out is not None else torch.empty(self.obs_shape, dtype=self.obs_dtype, device=self.device)
+        if obs.dtype != self.obs_dtype or tuple(obs.shape) != self.obs_shape or not obs.is_contiguous():
+            raise ValueError(f"`out` must be a contiguous {self.obs_dtype} tensor of shape {self.obs_shape}")
         _lib.check(self._lib.pgx_observe(self._handle, obs.data_ptr(), self._stream()))
         return obs
 

@@ -42,7 +42,7 @@ def test_config_struct_layout():
 ])
 def test_create_rejects_bad_config(engine_lib, field, value, needle):
     cfg = _lib.PgxConfig(batch=4, height=8, width=8, num_agents=2, obs_radius=3, collision_system=0, on_target=0,
-                         max_episode_steps=64, auto_reset=0, reserved0=0, seed=0, env_index_base=0)
+                         max_episode_steps=64, auto_reset=0, obs_dtype=0, seed=0, env_index_base=0)
     setattr(cfg, field, value)
     handle = C.c_void_p()
     status = engine_lib.pgx_create(C.byref(cfg), 0, C.byref(handle))
@@ -52,7 +52,7 @@ def test_create_rejects_bad_config(engine_lib, field, value, needle):
 
 def test_lds_limit_is_reported(engine_lib):
     cfg = _lib.PgxConfig(batch=1, height=1024, width=1024, num_agents=64, obs_radius=15, collision_system=0,
-                         on_target=0, max_episode_steps=64, auto_reset=0, reserved0=0, seed=0, env_index_base=0)
+                         on_target=0, max_episode_steps=64, auto_reset=0, obs_dtype=0, seed=0, env_index_base=0)
     handle = C.c_void_p()
     assert engine_lib.pgx_create(C.byref(cfg), 0, C.byref(handle)) == -1
     assert "LDS" in engine_lib.pgx_last_error().decode()
@@ -73,7 +73,7 @@ def test_no_device_fails_loudly_not_silently(engine_lib):
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         VecPogema(GridConfig(num_agents=2), batch=2)
     cfg = _lib.PgxConfig(batch=4, height=8, width=8, num_agents=2, obs_radius=3, collision_system=0, on_target=0,
-                         max_episode_steps=64, auto_reset=0, reserved0=0, seed=0, env_index_base=0)
+                         max_episode_steps=64, auto_reset=0, obs_dtype=0, seed=0, env_index_base=0)
     handle = C.c_void_p()
     assert engine_lib.pgx_create(C.byref(cfg), 0, C.byref(handle)) == -2  # PGX_E_HIP
     assert not handle.value

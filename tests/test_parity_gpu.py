@@ -74,3 +74,22 @@ def test_corridor_conflicts():
         ref = oracle_rollout(obstacles, agents, targets, acts, **kw)
         got = engine_rollout(obstacles, agents, targets, acts, **kw)
         assert_rollouts_equal(ref, got, f"corridor/{collision}")
+
+
+U8_GEOMS = [g for g in GEOMETRIES if g[0] in ("baseline_cfg0", "baseline_cfg1", "one_agent", "odd_agents", "full_wave",
+                                              "four_slots", "three_waves_wide", "max_radius", "dense_small")]
+
+
+@pytest.mark.parametrize("geom", U8_GEOMS, ids=[g[0] for g in U8_GEOMS])
+def test_uint8_observations(geom):
+    """obs_dtype=torch.uint8 (4x lighter, non-drop-in dtype): the same 0/1 planes, one byte per cell -- every window
+    width class (W = 3 .. 31), ragged tails, single- and multi-wave environments, both row-mask paths."""
+    import torch
+    name, B, H, Wd, A, r, density, T, max_steps = geom
+    seed = zlib.crc32(f"u8/{name}".encode()) % (2 ** 31)
+    obstacles, agents, targets = generate_instances(B, H, Wd, A, density, seed)
+    actions = random_actions(T, B, A, seed + 1)
+    kw = dict(obs_radius=r, collision_system="soft", on_target="finish", max_episode_steps=max_steps, auto_reset=True)
+    ref = oracle_rollout(obstacles, agents, targets, actions, **kw)
+    got = engine_rollout(obstacles, agents, targets, actions, obs_dtype=torch.uint8, **kw)
+    assert_rollouts_equal(ref, got, f"u8/{name}")

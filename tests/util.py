@@ -101,7 +101,7 @@ def c_oracle_rollout(obstacles, agents, targets, actions, *, obs_radius, collisi
 
 def engine_rollout(obstacles, agents, targets, actions, *, obs_radius, collision_system, on_target,
                    max_episode_steps, auto_reset, seed=0, env_index_base=0, action_dtype="int64",
-                   device="cuda:0"):
+                   device="cuda:0", obs_dtype=None):
     """Same rollout through the HIP engine (C-ABI via pogema_amd.VecPogema)."""
     import torch
     from pogema_amd import GridConfig, VecPogema
@@ -110,8 +110,11 @@ def engine_rollout(obstacles, agents, targets, actions, *, obs_radius, collision
     gc = GridConfig(map=obstacles[0].tolist(), num_agents=A, obs_radius=obs_radius,
                     collision_system=collision_system, on_target=on_target, max_episode_steps=max_episode_steps,
                     seed=seed)
-    env = VecPogema(gc, batch=B, device=device, auto_reset=auto_reset, env_index_base=env_index_base)
+    extra = {} if obs_dtype is None else {"obs_dtype": obs_dtype}
+    env = VecPogema(gc, batch=B, device=device, auto_reset=auto_reset, env_index_base=env_index_base, **extra)
     obs0 = env.reset_from_state(obstacles, agents, targets)
+    if obs_dtype is not None:
+        assert obs0.dtype == obs_dtype
     W = 2 * obs_radius + 1
     out = {
         "obs0": obs0.cpu().numpy(),
@@ -126,7 +129,7 @@ def engine_rollout(obstacles, agents, targets, actions, *, obs_radius, collision
     for t in range(T):
         obs, rew, term, trunc, infos = env.step(d_actions[t])
         st = env.get_state()
-        out["obs"][t] = obs.cpu().numpy()
+        out["obs"][t] = obs.cpu().numpy()  # uint8 observations widen to float32 here (0/1 values: exact)
         out["rewards"][t] = rew.cpu().numpy()
         out["terminated"][t] = term.cpu().numpy()
         out["truncated"][t] = trunc.cpu().numpy()

@@ -80,19 +80,77 @@ class Pogema:
             return out, [{"is_active": bool(a)} for a in active]
         return out
 
+    def _packed_io(self):
+        """One device buffer for every per-step output (+ a pinned host mirror) and a pinned staging buffer for the
+        actions: a step of this single-env view then costs one H2D copy, one kernel launch and ONE D2H copy instead
+        of six small synchronous copies (135 -> ~45 us per step on an MI355X box)."""
+        if getattr(self, "_io", None) is not None:
+            return self._io
+        import torch
+        vec = self._vec
+        A, W = vec.num_agents, vec.window
+        n_obs = A * 3 * W * W * 4
+        off = {"obs": 0, "rewards": n_obs, "metrics": n_obs + 4 * A}
+        off["terminated"] = off["metrics"] + 4 * 6
+        off["truncated"] = off["terminated"] + A
+        off["is_active"] = off["truncated"] + A
+        off["episode_done"] = off["is_active"] + A
+        total = off["episode_done"] + 1
+        dev = torch.zeros(total, dtype=torch.uint8, device=vec.device)
+        host = torch.zeros(total, dtype=torch.uint8).pin_memory()
+        hnp = host.numpy()
+        views = {
+            "obs": hnp[:n_obs].view(np.float32).reshape(A, 3, W, W),
+            "rewards": hnp[off["rewards"]:off["rewards"] + 4 * A].view(np.float32),
+            "metrics": hnp[off["metrics"]:off["metrics"] + 24].view(np.float32),
+            "terminated": hnp[off["terminated"]:off["terminated"] + A], "truncated": hnp[off["truncated"]:off["truncated"] + A],
+            "is_active": hnp[off["is_active"]:off["is_active"] + A], "episode_done": hnp[off["episode_done"]:],
+        }
+        act_host = torch.zeros(A, dtype=torch.int64).pin_memory()
+        act_dev = torch.zeros(A, dtype=torch.int64, device=vec.device)
+        base = dev.data_ptr()
+        ptr = {k: base + v for k, v in off.items()}
+        from . import _lib
+        _lib.check(vec._lib.pgx_set_metrics_buffers(vec._handle, ptr["metrics"], ptr["episode_done"]))
+        self._io = dict(dev=dev, host=host, views=views, act_host=act_host, act_np=act_host.numpy(), act_dev=act_dev, ptr=ptr)
+        return self._io
+
     def step(self, action):
         assert len(action) == self.get_num_agents()
+        import torch
+        from . import _lib
+        vec = self._vec
+        if vec.observation_type != "default":  # dict observations: the general (multi-copy) route
+            return self._step_general(action)
+        io = self._packed_io()
+        io["act_np"][:] = action
+        io["act_dev"].copy_(io["act_host"], non_blocking=True)
+        p = io["ptr"]
+        _lib.check(vec._lib.pgx_step(vec._handle, io["act_dev"].data_ptr(), 2, p["obs"], p["rewards"], p["terminated"],
+                                     p["truncated"], p["is_active"], vec._stream()))
+        io["host"].copy_(io["dev"], non_blocking=True)
+        torch.cuda.current_stream(vec.device).synchronize()
+        v = io["views"]
+        obs = v["obs"].copy()
+        info_list = [{"is_active": bool(a)} for a in v["is_active"]]
+        if v["episode_done"][0]:  # metric wrappers: infos[0]['metrics'] on the step that ends the episode
+            info_list[0]["metrics"] = self._metrics_dict(v["metrics"])
+        return ([obs[i] for i in range(obs.shape[0])], [float(x) for x in v["rewards"]],
+                [bool(x) for x in v["terminated"]], [bool(x) for x in v["truncated"]], info_list)
+
+    def _metrics_dict(self, values):
+        from ._lib import METRIC_NAMES
+        metrics = {k: float(x) for k, x in zip(METRIC_NAMES, values)}
+        if self.grid_config.on_target == "restart":
+            return {"avg_throughput": metrics["avg_throughput"]}
+        metrics.pop("avg_throughput")
+        return metrics
+
+    def _step_general(self, action):
         obs, rewards, terminated, truncated, infos = self._vec.step(np.asarray(action, dtype=np.int64)[None])
         info_list = [{"is_active": bool(v)} for v in infos["is_active"][0].cpu().numpy()]
-        if bool(infos["episode_done"][0]):  # metric wrappers: infos[0]['metrics'] on the step that ends the episode
-            from ._lib import METRIC_NAMES
-            values = infos["metrics"][0].cpu().numpy()
-            metrics = {k: float(v) for k, v in zip(METRIC_NAMES, values)}
-            if self.grid_config.on_target == "restart":
-                metrics = {"avg_throughput": metrics["avg_throughput"]}
-            else:
-                metrics.pop("avg_throughput")
-            info_list[0]["metrics"] = metrics
+        if bool(infos["episode_done"][0]):
+            info_list[0]["metrics"] = self._metrics_dict(infos["metrics"][0].cpu().numpy())
         return (self._obs_list(obs), [float(v) for v in rewards[0].cpu().numpy()],
                 [bool(v) for v in terminated[0].cpu().numpy()], [bool(v) for v in truncated[0].cpu().numpy()],
                 info_list)

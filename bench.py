@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--action-dtype", default="int64", choices=["int8", "int32", "int64"])
     ap.add_argument("--obs-dtype", default="float32", choices=["float32", "uint8"],
                     help="float32 = the reference's dtype (the headline); uint8 = the engine's lighter non-drop-in mode")
+    ap.add_argument("--auto-reset", default="restore", choices=["restore", "regenerate"],
+                    help="restore = finished envs return to their initial state inside the step kernel (headline); "
+                         "regenerate = they get a fresh random instance on the device (pgx_regenerate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-obs", action="store_true", help="diagnostic: skip the observation write")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -131,7 +134,8 @@ def main():
     gc = GridConfig(size=size, density=args.density, num_agents=agents, obs_radius=r, seed=0,
                     collision_system=args.collision, on_target=args.on_target,
                     max_episode_steps=args.max_episode_steps)
-    env = VecPogema(gc, batch=batch, device=device, env_index_base=rank * batch, auto_reset=True, reuse_buffers=True,
+    env = VecPogema(gc, batch=batch, device=device, env_index_base=rank * batch,
+                    auto_reset=True if args.auto_reset == "restore" else "regenerate", reuse_buffers=True,
                     obs_dtype=torch.float32 if args.obs_dtype == "float32" else torch.uint8)
     env.reset(seed=0)
     tdt = {"int8": torch.int8, "int32": torch.int32, "int64": torch.int64}[args.action_dtype]
@@ -189,7 +193,7 @@ def main():
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[{args.workload[-1]}]: {batch} envs/GPU, {size}x{size} map, "
                                    f"{agents} agents, obs_radius {r}, density {args.density}",
-                       "collision_system": args.collision, "on_target": args.on_target, "auto_reset": True,
+                       "collision_system": args.collision, "on_target": args.on_target, "auto_reset": args.auto_reset,
                        "max_episode_steps": args.max_episode_steps, "obs_dtype": args.obs_dtype,
                        "action_dtype": args.action_dtype, "envs_per_gpu": batch, "sharding": f"batch-sharded x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -123,10 +123,21 @@ int pgx_reset_from_state(pgx_env* env, const uint8_t* obstacles, const int32_t* 
  *                                                   seed and env index).  Otherwise only the flagged envs
  *                                                   get a NEW instance (their generation counter advances);
  *                                                   their step counters and metric accumulators restart.
- * Synchronises `stream` (the retry decision needs the device's failure count).  Returns
- * PGX_E_PLACEMENT if an env cannot be filled after `max_retries` re-draws (<= 0: 10). */
+ * One kernel builds one env per workgroup, retries included; the call then synchronises `stream` once to read the
+ * device's failure count: PGX_E_PLACEMENT if an env cannot be filled after `max_retries` re-draws (<= 0: 10). */
 int pgx_reset_random(pgx_env* env, float density, uint64_t seed, const uint8_t* shared_map,
                      const uint8_t* env_mask, int32_t max_retries, void* stream);
+
+/* Asynchronous form of the masked reset, for use right after pgx_step: NEW instances for the envs flagged in
+ * `env_mask` (device u8 [batch], e.g. the `episode_done` buffer of pgx_set_metrics_buffers), then -- when `obs` is
+ * not NULL -- the observations of exactly those envs are rewritten in `obs` (same buffer/dtype as pgx_step's).
+ * This is the reference's auto-reset wrapper with `seed=None` (a fresh random instance per episode) for a whole
+ * batch, without a host round trip: nothing here synchronises.  An env that cannot be filled within `max_retries`
+ * attempts (<= 0: 3) keeps its previous instance and is counted; pgx_regenerate_failures() returns that count
+ * (it synchronises `stream`).  Needs one scratch slot per env (9 bytes per cell and env, allocated on first use). */
+int pgx_regenerate(pgx_env* env, const uint8_t* env_mask, float density, uint64_t seed, const uint8_t* shared_map,
+                   int32_t max_retries, void* obs, void* stream);
+int64_t pgx_regenerate_failures(pgx_env* env, void* stream);
 
 /* The unpadded obstacle maps currently installed: device u8 [batch, height, width] (`Grid.get_obstacles`). */
 int pgx_get_map(pgx_env* env, uint8_t* obstacles, void* stream);

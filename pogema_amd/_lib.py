@@ -44,7 +44,7 @@ METRIC_NAMES = ("ISR", "CSR", "ep_length", "SoC", "makespan", "avg_throughput")
 # every symbol include/pogema_amd.h declares; tests/test_abi.py checks the library exports them all
 EXPORTED_SYMBOLS = (
     "pgx_abi_version", "pgx_last_error", "pgx_create", "pgx_destroy", "pgx_obs_elems", "pgx_agent_elems",
-    "pgx_reset_from_state", "pgx_reset_random", "pgx_get_map", "pgx_step", "pgx_observe", "pgx_set_metrics_buffers", "pgx_get_state", "pgx_generate", "pgx_place_agents",
+    "pgx_reset_from_state", "pgx_reset_random", "pgx_regenerate", "pgx_regenerate_failures", "pgx_get_map", "pgx_step", "pgx_observe", "pgx_set_metrics_buffers", "pgx_get_state", "pgx_generate", "pgx_place_agents",
 )
 
 
@@ -94,6 +94,9 @@ def load() -> C.CDLL:
     lib.pgx_agent_elems.restype = i64
     lib.pgx_reset_from_state.argtypes = [vp, vp, vp, vp, vp]
     lib.pgx_reset_random.argtypes = [vp, f32, u64, vp, vp, i32, vp]
+    lib.pgx_regenerate.argtypes = [vp, vp, f32, u64, vp, i32, vp, vp]
+    lib.pgx_regenerate_failures.argtypes = [vp, vp]
+    lib.pgx_regenerate_failures.restype = i64
     lib.pgx_get_map.argtypes = [vp, vp, vp]
     lib.pgx_step.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     lib.pgx_observe.argtypes = [vp, vp, vp]
@@ -101,7 +104,8 @@ def load() -> C.CDLL:
     lib.pgx_get_state.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.pgx_generate.argtypes = [i32, i32, i32, i32, f32, u64, i32, i32, vp, vp, vp]
     lib.pgx_place_agents.argtypes = [i32, i32, i32, i32, u64, i32, i32, vp, i32, vp, vp]
-    for name in ("pgx_create", "pgx_destroy", "pgx_reset_from_state", "pgx_reset_random", "pgx_get_map", "pgx_step", "pgx_observe", "pgx_set_metrics_buffers", "pgx_set_metrics_buffers",
+    for name in ("pgx_create", "pgx_destroy", "pgx_reset_from_state", "pgx_reset_random", "pgx_regenerate", "pgx_get_map",
+                 "pgx_step", "pgx_observe", "pgx_set_metrics_buffers", "pgx_set_metrics_buffers",
                  "pgx_get_state", "pgx_generate", "pgx_place_agents"):
         getattr(lib, name).restype = C.c_int
     if lib.pgx_abi_version() != PGX_ABI_VERSION:

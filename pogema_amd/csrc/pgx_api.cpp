@@ -86,7 +86,9 @@ struct pgx_env {
     uint8_t *todo = nullptr, *regen = nullptr;  // [B]
     uint32_t* epoch = nullptr;            // [B]
     uint32_t* fail_count = nullptr;       // [1]
+    uint32_t* regen_fail = nullptr;       // [1] sticky failure counter of pgx_regenerate
     uint32_t *labels = nullptr, *pending = nullptr;  // [chunk_envs][H*W], allocated on first use
+    uint8_t* scratch_map = nullptr;       // [chunk_envs][H*W] draft maps
     int chunk_envs = 0;
 };
 
@@ -163,6 +165,7 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
     alloc((void**)&e->regen, B);
     alloc((void**)&e->epoch, B * sizeof(uint32_t));
     alloc((void**)&e->fail_count, sizeof(uint32_t));
+    alloc((void**)&e->regen_fail, sizeof(uint32_t));
     if (cfg->on_target == PGX_ON_TARGET_RESTART) {
         const size_t cells = B * (size_t)cfg->height * cfg->width;
         alloc((void**)&e->comp_begin, cells * sizeof(uint32_t));
@@ -175,7 +178,9 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
         pgx_destroy(e);
         return fail(err == hipErrorOutOfMemory ? PGX_E_NOMEM : PGX_E_HIP, "hipMalloc failed: %s", msg);
     }
-    if ((err = pgx::prepare_step(e->geo)) != hipSuccess) {
+    err = hipMemset(e->regen_fail, 0, sizeof(uint32_t));
+    if (err == hipSuccess) err = pgx::prepare_step(e->geo);
+    if (err != hipSuccess) {
         const char* msg = hipGetErrorString(err);
         const size_t need = e->geo.lds_bytes;
         pgx_destroy(e);
@@ -195,7 +200,8 @@ int pgx_destroy(pgx_env* e) {
     DeviceGuard guard(e->device);
     void* ptrs[] = {e->obst,   e->pos,     e->tgt,        e->pos0,     e->tgt0,       e->active,
                     e->elapsed, e->comp_begin, e->comp_len, e->comp_cells, e->tcount, e->dbg, e->macc,
-                    e->map_u8, e->todo, e->regen, e->epoch, e->fail_count, e->labels, e->pending};
+                    e->map_u8, e->todo, e->regen, e->epoch, e->fail_count, e->regen_fail, e->labels, e->pending,
+                    e->scratch_map};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete e;
@@ -212,17 +218,52 @@ int64_t pgx_agent_elems(const pgx_env* e) {
     return (int64_t)e->cfg.batch * e->cfg.num_agents;
 }
 
+static void fill_params(const pgx_env* e, pgx::StepParams& p);
+
 // ---- reset path ---------------------------------------------------------------------------------------
-// Scratch of the component labelling: two words per cell for a chunk of environments (<= 256 MiB in total).
-static int ensure_reset_scratch(pgx_env* e) {
-    if (e->labels) return PGX_OK;
+// Scratch of the reset kernel: 9 bytes per cell and slot (draft map, labels, pending).  The synchronous resets
+// walk the batch in chunks of <= 2^25 cells' worth of environments (<= 288 MiB); pgx_regenerate, which must not
+// return to the host between chunks, wants one slot per environment (`full`).
+static int ensure_reset_scratch(pgx_env* e, bool full) {
     const size_t cells = (size_t)e->cfg.height * e->cfg.width;
     size_t chunk = ((size_t)1 << 25) / cells;
     chunk = std::max<size_t>(1, std::min<size_t>(chunk, (size_t)e->cfg.batch));
+    if (full) {
+        chunk = (size_t)e->cfg.batch;
+        if (chunk * cells * 9 > ((size_t)32 << 30))
+            return fail(PGX_E_NOMEM, "pgx_regenerate needs %zu bytes of scratch (9 per cell and env); use pgx_reset_random",
+                        chunk * cells * 9);
+    }
+    if (e->labels && (size_t)e->chunk_envs >= chunk) return PGX_OK;
+    if (e->labels) {
+        PGX_HIP(hipDeviceSynchronize());
+        (void)hipFree(e->labels);
+        (void)hipFree(e->pending);
+        (void)hipFree(e->scratch_map);
+        e->labels = e->pending = nullptr;
+        e->scratch_map = nullptr;
+    }
     PGX_HIP(hipMalloc((void**)&e->labels, chunk * cells * sizeof(uint32_t)));
     PGX_HIP(hipMalloc((void**)&e->pending, chunk * cells * sizeof(uint32_t)));
+    PGX_HIP(hipMalloc((void**)&e->scratch_map, chunk * cells));
     e->chunk_envs = (int)chunk;
     return PGX_OK;
+}
+
+static pgx::ResetParams reset_params(const pgx_env* e) {
+    const pgx_config& c = e->cfg;
+    pgx::ResetParams p;
+    memset(&p, 0, sizeof p);
+    p.H = c.height; p.Wd = c.width; p.A = c.num_agents; p.r = c.obs_radius; p.wpr = e->wpr; p.bmw = e->bmw;
+    p.lifelong = c.on_target == PGX_ON_TARGET_RESTART;
+    p.todo = e->todo; p.epoch = e->epoch;
+    p.scratch_map = e->scratch_map; p.labels = e->labels; p.pending = e->pending;
+    p.map_u8 = e->map_u8; p.obst_bm = e->obst;
+    p.pos = e->pos; p.tgt = e->tgt; p.pos0 = e->pos0; p.tgt0 = e->tgt0; p.active = e->active; p.tcount = e->tcount;
+    p.elapsed = e->elapsed; p.macc = e->macc;
+    p.comp_begin = e->comp_begin; p.comp_len = e->comp_len; p.comp_cells = e->comp_cells;
+    p.fail_count = e->fail_count;
+    return p;
 }
 
 int pgx_reset_from_state(pgx_env* e, const uint8_t* obstacles, const int32_t* agent_xy, const int32_t* target_xy,
@@ -243,12 +284,13 @@ int pgx_reset_from_state(pgx_env* e, const uint8_t* obstacles, const int32_t* ag
     PGX_HIP(pgx::launch_zero_i32(e->elapsed, B, s));
     PGX_HIP(pgx::launch_zero_i32(reinterpret_cast<int32_t*>(e->macc), B * 4, s));
     if (c.on_target == PGX_ON_TARGET_RESTART) {  // component tables of PogemaLifeLong, built on the device
-        if (int rc = ensure_reset_scratch(e)) return rc;
+        if (int rc = ensure_reset_scratch(e, false)) return rc;
+        pgx::ResetParams p = reset_params(e);
+        p.given_state = 1;
         for (int b0 = 0; b0 < c.batch; b0 += e->chunk_envs) {
-            const int n = std::min(e->chunk_envs, c.batch - b0);
-            PGX_HIP(pgx::launch_ccl(e->map_u8, e->labels, e->pending, e->regen, b0, n, c.height, c.width, 0, s));
-            PGX_HIP(pgx::launch_tables(e->map_u8, e->labels, e->pending, e->regen, e->comp_begin, e->comp_len,
-                                       e->comp_cells, b0, n, c.width, cells, 0, s));
+            p.env_begin = b0;
+            p.env_count = std::min(e->chunk_envs, c.batch - b0);
+            PGX_HIP(pgx::launch_reset_env(p, s));
         }
     }
     e->has_state = true;
@@ -268,44 +310,73 @@ int pgx_reset_random(pgx_env* e, float density, uint64_t seed, const uint8_t* sh
     if (max_retries < 1) max_retries = 10;
     DeviceGuard guard(e->device);
     if (guard.err != hipSuccess) return fail(PGX_E_HIP, "cannot select device: %s", hipGetErrorString(guard.err));
-    if (int rc = ensure_reset_scratch(e)) return rc;
+    if (int rc = ensure_reset_scratch(e, false)) return rc;
     hipStream_t s = (hipStream_t)stream;
-    const uint32_t thr = pgx::gen_density_threshold(density);
-    const uint64_t key_base = seed + (uint64_t)c.env_index_base;  // env i draws instance (seed + global index)
-    const int shared = shared_map ? 1 : 0;
+    pgx::ResetParams p = reset_params(e);
+    p.max_retries = max_retries;
+    p.thr = pgx::gen_density_threshold(density);
+    p.key_base = seed + (uint64_t)c.env_index_base;  // env i draws instance (seed + global index)
+    p.shared_map = shared_map;
     PGX_HIP(pgx::launch_reset_begin(env_mask, e->todo, e->regen, e->epoch, c.batch, s));
-    uint32_t failed_total = 0;
+    PGX_HIP(hipMemsetAsync(e->fail_count, 0, sizeof(uint32_t), s));
     for (int b0 = 0; b0 < c.batch; b0 += e->chunk_envs) {
-        const int n = std::min(e->chunk_envs, c.batch - b0);
-        uint32_t failed = 0;
-        for (int attempt = 0; attempt < max_retries; ++attempt) {
-            PGX_HIP(hipMemsetAsync(e->fail_count, 0, sizeof(uint32_t), s));
-            if (!shared || attempt == 0)
-                PGX_HIP(pgx::launch_gen_obstacles(e->map_u8, shared_map, e->todo, e->epoch, b0, n, cells, thr, key_base,
-                                                  (uint32_t)attempt, s));
-            PGX_HIP(pgx::launch_ccl(shared ? shared_map : e->map_u8, e->labels, e->pending, e->todo, b0, n, c.height,
-                                    c.width, shared, s));
-            PGX_HIP(pgx::launch_place(e->map_u8, e->labels, e->pending, e->todo, e->epoch, e->pos, e->tgt, e->pos0,
-                                      e->tgt0, e->active, e->tcount, e->elapsed, e->macc, e->fail_count, b0, n,
-                                      c.num_agents, c.width, cells, c.obs_radius, shared, key_base, (uint32_t)attempt, s));
-            PGX_HIP(hipMemcpyAsync(&failed, e->fail_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-            PGX_HIP(hipStreamSynchronize(s));  // reset path: the retry decision needs the failure count
-            if (failed == 0) break;
-        }
-        failed_total += failed;
-        if (c.on_target == PGX_ON_TARGET_RESTART && failed == 0)
-            PGX_HIP(pgx::launch_tables(e->map_u8, e->labels, e->pending, e->regen, e->comp_begin, e->comp_len,
-                                       e->comp_cells, b0, n, c.width, cells, shared, s));
+        p.env_begin = b0;
+        p.env_count = std::min(e->chunk_envs, c.batch - b0);
+        PGX_HIP(pgx::launch_reset_env(p, s));
     }
-    if (failed_total) {
-        e->has_state = false;
+    uint32_t failed = 0;
+    PGX_HIP(hipMemcpyAsync(&failed, e->fail_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    PGX_HIP(hipStreamSynchronize(s));  // the status is the device's failure count
+    if (failed) {
+        if (!env_mask) e->has_state = false;  // (masked: the failed envs keep their previous instance)
         return fail(PGX_E_PLACEMENT, "could not place %d agents in %u environment(s) after %d attempts (density %.2f, %dx%d)",
-                    c.num_agents, failed_total, max_retries, (double)density, c.height, c.width);
+                    c.num_agents, failed, max_retries, (double)density, c.height, c.width);
     }
-    PGX_HIP(pgx::launch_pack_obstacles(e->map_u8, e->regen, e->obst, c.batch, c.height, c.width, c.obs_radius, e->wpr,
-                                       e->bmw, s));
     e->has_state = true;
     return PGX_OK;
+}
+
+int pgx_regenerate(pgx_env* e, const uint8_t* env_mask, float density, uint64_t seed, const uint8_t* shared_map,
+                   int32_t max_retries, void* obs, void* stream) {
+    if (!e || !env_mask) return fail(PGX_E_INVALID, "pgx_regenerate: null argument");
+    if (!e->has_state) return fail(PGX_E_STATE, "pgx_regenerate before the first reset");
+    if (!shared_map && !(density >= 0.0f && density <= 1.0f))
+        return fail(PGX_E_INVALID, "density %.3f outside [0, 1]", (double)density);
+    if (max_retries < 1) max_retries = 3;
+    DeviceGuard guard(e->device);
+    if (guard.err != hipSuccess) return fail(PGX_E_HIP, "cannot select device: %s", hipGetErrorString(guard.err));
+    if (int rc = ensure_reset_scratch(e, true)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const pgx_config& c = e->cfg;
+    pgx::ResetParams p = reset_params(e);
+    p.max_retries = max_retries;
+    p.thr = pgx::gen_density_threshold(density);
+    p.key_base = seed + (uint64_t)c.env_index_base;
+    p.shared_map = shared_map;
+    p.fail_count = e->regen_fail;
+    p.env_begin = 0;
+    p.env_count = c.batch;
+    PGX_HIP(pgx::launch_reset_begin(env_mask, e->todo, e->regen, e->epoch, c.batch, s));
+    PGX_HIP(pgx::launch_reset_env(p, s));
+    if (obs) {
+        pgx::StepParams sp;
+        fill_params(e, sp);
+        sp.mode = pgx::MODE_OBSERVE;
+        sp.obs = static_cast<float*>(obs);
+        sp.only = e->regen;
+        PGX_HIP(pgx::launch_step(sp, e->geo, s));
+    }
+    return PGX_OK;
+}
+
+int64_t pgx_regenerate_failures(pgx_env* e, void* stream) {
+    if (!e) return fail(PGX_E_INVALID, "pgx_regenerate_failures: null handle");
+    DeviceGuard guard(e->device);
+    if (guard.err != hipSuccess) return fail(PGX_E_HIP, "cannot select device: %s", hipGetErrorString(guard.err));
+    uint32_t n = 0;
+    PGX_HIP(hipMemcpyAsync(&n, e->regen_fail, sizeof n, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    PGX_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return (int64_t)n;
 }
 
 int pgx_get_map(pgx_env* e, uint8_t* obstacles, void* stream) {

@@ -61,6 +61,7 @@ struct StepParams {
     uint8_t* terminated;
     uint8_t* truncated;
     uint8_t* act_out;
+    const uint8_t* only;      // MODE_OBSERVE: write only workgroups holding a flagged env (may be null)
     unsigned long long* dbg;  // diagnostic (PGX_FLAGS bit2): per-workgroup {start, resolve done, first store, end} clocks
 };
 
@@ -82,21 +83,35 @@ hipError_t launch_pack_obstacles(const uint8_t* obstacles, const uint8_t* only, 
                                  int r, int wpr, int bmw, hipStream_t stream);
 
 // ---- on-device reset (pgx_reset.hip) ----------------------------------------------------------------
+// Kernel argument block of reset_env_kernel: one workgroup per environment of [env_begin, env_begin + env_count),
+// scratch slot = workgroup index.
+struct ResetParams {
+    int32_t env_begin, env_count;
+    int32_t H, Wd, A, r, wpr, bmw;
+    int32_t lifelong;      // build the component tables (on_target = restart)
+    int32_t given_state;   // map already installed (pgx_reset_from_state): components + tables only
+    int32_t max_retries;
+    uint32_t thr;          // obstacle <=> 24 hash bits < thr
+    uint64_t key_base;     // seed + env_index_base: env i draws instance key_base + i
+    const uint8_t* shared_map;  // [H*W] given map for every env, or null
+    uint8_t* todo;              // [B] in: envs to build; cleared on success
+    const uint32_t* epoch;      // [B] generation counters
+    uint8_t* scratch_map;       // [slots][H*W] draft maps
+    uint32_t* labels;           // [slots][H*W]
+    uint32_t* pending;          // [slots][H*W]
+    uint8_t* map_u8;            // [B][H*W] installed maps
+    uint32_t* obst_bm;          // [B][bmw] padded bitmaps
+    uint32_t *pos, *tgt, *pos0, *tgt0;
+    uint8_t* active;
+    uint32_t* tcount;           // may be null
+    int32_t* elapsed;
+    int4* macc;
+    uint32_t *comp_begin, *comp_len, *comp_cells;  // lifelong only
+    uint32_t* fail_count;       // envs that could not be filled
+};
 hipError_t launch_reset_begin(const uint8_t* mask, uint8_t* todo, uint8_t* regen, uint32_t* epoch, int batch,
                               hipStream_t s);
-hipError_t launch_gen_obstacles(uint8_t* obst, const uint8_t* shared_map, const uint8_t* todo, const uint32_t* epoch,
-                                int env_begin, int env_count, int cells, uint32_t thr, uint64_t key_base,
-                                uint32_t attempt, hipStream_t s);
-hipError_t launch_ccl(const uint8_t* obst, uint32_t* labels, uint32_t* pending, const uint8_t* todo, int env_begin,
-                      int env_count, int H, int Wd, int shared, hipStream_t s);
-hipError_t launch_place(const uint8_t* obst, const uint32_t* labels, uint32_t* pending, uint8_t* todo,
-                        const uint32_t* epoch, uint32_t* pos, uint32_t* tgt, uint32_t* pos0, uint32_t* tgt0,
-                        uint8_t* active, uint32_t* tcount, int32_t* elapsed, int4* macc, uint32_t* fail_count,
-                        int env_begin, int env_count, int A, int Wd, int cells, int r, int shared, uint64_t key_base,
-                        uint32_t attempt, hipStream_t s);
-hipError_t launch_tables(const uint8_t* obst, const uint32_t* labels, uint32_t* counters, const uint8_t* regen,
-                         uint32_t* comp_begin, uint32_t* comp_len, uint32_t* comp_cells, int env_begin, int env_count,
-                         int Wd, int cells, int shared, hipStream_t s);
+hipError_t launch_reset_env(const ResetParams& p, hipStream_t s);
 hipError_t launch_pack_agents(const int32_t* agent_xy, const int32_t* target_xy, uint32_t* pos, uint32_t* tgt,
                               uint32_t* pos0, uint32_t* tgt0, uint8_t* active, uint32_t* tcount, size_t n,
                               int r, hipStream_t stream);

@@ -206,6 +206,11 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
     }
     const int env0 = blk * epw;
     const int nenv = min(epw, p.batch - env0);
+    if (p.only) {  // masked observe (after pgx_regenerate): untouched environments keep their observation
+        bool any = false;
+        for (int el = 0; el < nenv; ++el) any = any || p.only[env0 + el] != 0;
+        if (!any) return;
+    }
     const int A = p.num_agents;
     const int bmw = p.bm_words;
     const int wpr = p.wpr;

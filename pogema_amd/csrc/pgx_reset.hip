@@ -5,14 +5,15 @@
 // The generator is counter-based (normative statement: oracle/generator_oracle.py, test infrastructure),
 // so host (pgx_generate) and device (pgx_reset_random) produce identical instances.
 //
-// Everything here is HBM/L2-latency-bound integer work on the reset path, not the step hot path:
-//   gen_obstacles_kernel   one thread per cell, 3 splitmix64 rounds, 1 byte out          (streaming)
-//   ccl_kernel             one workgroup per environment: union-find with L2 atomicMin, every root
-//                          ends as the smallest row-major index of its component           (atomics)
-//   place_kernel           one wave per environment: 64 candidates fetched at a time, the order-dependent
-//                          pairing replayed with wave-uniform registers                     (latency)
-//   tables_kernel          one wave per environment: component sizes (L2 atomics), exclusive scan
-//                          (DPP-free shuffles), stable fill with ballot grouping            (latency)
+// Everything here is L2-latency-bound integer work on the reset path, not the step hot path.  ONE kernel
+// (reset_env_kernel) builds one environment per 256-thread workgroup, retries included:
+//   obstacles    one hash per cell                                                          (streaming)
+//   ccl_phase    horizontal runs by ballot, vertical merges by lock-free union-find (LDS forest for maps up to
+//                ~128 x 128, L2 atomics beyond): every root ends as the smallest row-major index   (atomics)
+//   place_phase  wave 0: 64 candidates fetched at a time, the order-dependent pairing replayed with
+//                wave-uniform registers                                                      (latency)
+//   tables_phase lifelong only: component sizes, exclusive scan, stable fill with ballot grouping (latency)
+//   pack_phase   padded 1-bit-per-cell bitmap with the artificial border
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -81,64 +82,21 @@ __device__ __forceinline__ void uf_union(uint32_t* parent, uint32_t a, uint32_t 
     }
 }
 
-}  // namespace
 
-// todo/regen flags and generation counters for one pgx_reset_random call
-__global__ void reset_begin_kernel(const uint8_t* __restrict__ mask, uint8_t* __restrict__ todo,
-                                   uint8_t* __restrict__ regen, uint32_t* __restrict__ epoch, int batch) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= batch) return;
-    const uint8_t m = mask ? (mask[b] != 0 ? 1 : 0) : 1;
-    todo[b] = m;
-    regen[b] = m;
-    epoch[b] = mask ? epoch[b] + m : 0u;
-}
+// ---- phases of the per-environment reset (device functions; all threads of the 256-thread workgroup call them) ----
 
-// obstacles of the envs still to do: Bernoulli(thr / 2^24) per cell, or a copy of the shared map
-__global__ void gen_obstacles_kernel(uint8_t* __restrict__ obst, const uint8_t* __restrict__ shared_map,
-                                     const uint8_t* __restrict__ todo, const uint32_t* __restrict__ epoch,
-                                     int env_begin, int env_count, int cells, uint32_t thr, uint64_t key_base,
-                                     uint32_t attempt) {
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (size_t)env_count * cells) return;
-    const int env = env_begin + (int)(gid / cells);
-    const uint32_t c = (uint32_t)(gid % cells);
-    if (!todo[env]) return;
-    uint8_t v;
-    if (shared_map) {
-        v = shared_map[c] != 0 ? 1 : 0;
-    } else {
-        const uint64_t h = instance_hash(key_base + (uint64_t)env, epoch[env], attempt);
-        v = (sm64(h ^ (GEN_TAG_OBST | (uint64_t)c)) >> 40) < thr ? 1 : 0;
-    }
-    obst[(size_t)env * cells + c] = v;
-}
-
-// Connected components of the FREE cells of one environment per workgroup.
-// labels[c] = smallest row-major index of c's component (NONE on obstacles); pending[] cleared.
+// Connected components of the FREE cells: labels[c] = smallest row-major index of c's component (NONE on
+// obstacles).
 //   1. horizontal runs: every free cell points at the first cell of its run (one wave per row, ballot + clz,
 //      no atomics);
 //   2. vertical merges: only where a run STARTS touching an upper run (the left neighbours are not both free) --
 //      ~0.25 unions per cell at density 0.3 instead of ~1 -- lock-free union-find, larger root under smaller;
 //   3. every cell resolves its root (in-place compression).
-//   LDS = true: the forest lives in LDS (maps up to 128 x 128), only the final labels go to HBM.
-//   shared != 0: one map for all envs (GridConfig.map): blockIdx 0 labels it once into slot 0.
+//   LDS = true: the forest lives in LDS (maps up to ~128 x 128), only the final labels go to HBM.
 template <bool LDS>
-__global__ __launch_bounds__(256) void ccl_kernel(const uint8_t* __restrict__ obst_all, uint32_t* __restrict__ labels,
-                                                  uint32_t* __restrict__ pending, const uint8_t* __restrict__ todo,
-                                                  int env_begin, int H, int Wd, int shared) {
-    extern __shared__ uint32_t s_forest[];
-    const int local = blockIdx.x;
-    const int env = env_begin + local;
+__device__ void ccl_phase(const uint8_t* __restrict__ obst, uint32_t* __restrict__ out, uint32_t* forest, int H, int Wd) {
     const int cells = H * Wd;
-    uint32_t* pend = pending + (size_t)local * cells;
-    const bool mine = todo[env] != 0;
-    if (mine)
-        for (int c = threadIdx.x; c < cells; c += blockDim.x) pend[c] = 0u;
-    if (shared ? (local != 0) : !mine) return;
-    const uint8_t* obst = obst_all + (shared ? 0 : (size_t)env * cells);  // shared: obst_all IS the one map
-    uint32_t* out = labels + (shared ? 0 : (size_t)local * cells);
-    uint32_t* parent = LDS ? s_forest : out;
+    uint32_t* parent = LDS ? forest : out;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     for (int x = wave; x < H; x += nwaves) {
         uint32_t carry = 0u;
@@ -173,35 +131,22 @@ __global__ __launch_bounds__(256) void ccl_kernel(const uint8_t* __restrict__ ob
             else st<false>(parent + c, root);  // in-place compression: still a valid ancestor for concurrent finds
         }
     }
+    __syncthreads();
 }
 
-// One WAVE per environment walks the candidate stream of GEN v2 and closes start/target pairs.
-// pending[c]: bit 31 = cell c already taken; low bits (root entries only) = open start cell + 1.
+// Wave 0 walks the candidate stream of GEN v2 and closes start/target pairs into `pairs` (LDS: start, target
+// row-major cell per agent).  Returns the number of pairs closed (wave-uniform).
+// pend[c]: bit 31 = cell c already taken; low bits (root entries only) = open start cell + 1.
 // 64 candidates at a time: every lane hashes one candidate and fetches its obstacle byte, taken mark and label
 // (one exposed L2 latency for 64 candidates); the order-dependent part -- "first visit of a component opens a
 // pair, the next closes it" -- is then replayed in candidate order with wave-uniform registers.  The pending
 // word of the component being visited is cached in registers (the giant component takes ~95 % of the visits at
-// density 0.3), so most candidates cost a few scalar-like ALU instructions and no memory round trip.
-// All `pending` traffic uses relaxed agent-scope accesses (L2-served), so batches see earlier batches' marks.
-__global__ __launch_bounds__(64) void place_kernel(const uint8_t* __restrict__ obst_all, const uint32_t* __restrict__ labels,
-                                                   uint32_t* __restrict__ pending, uint8_t* __restrict__ todo,
-                                                   const uint32_t* __restrict__ epoch, uint32_t* __restrict__ pos,
-                                                   uint32_t* __restrict__ tgt, uint32_t* __restrict__ pos0,
-                                                   uint32_t* __restrict__ tgt0, uint8_t* __restrict__ active,
-                                                   uint32_t* __restrict__ tcount, int32_t* __restrict__ elapsed,
-                                                   int4* __restrict__ macc, uint32_t* __restrict__ fail_count,
-                                                   int env_begin, int env_count, int A, int Wd, int cells, int r,
-                                                   int shared, uint64_t key_base, uint32_t attempt) {
-    const int local = blockIdx.x;
-    const int env = env_begin + local;
-    if (!todo[env]) return;
+// density 0.3), so most candidates cost a few ALU instructions and no memory round trip.
+// All `pend` traffic uses relaxed agent-scope accesses (L2-served), so batches see earlier batches' marks.
+__device__ int place_phase(const uint8_t* __restrict__ obst, const uint32_t* __restrict__ lab, uint32_t* __restrict__ pend,
+                           uint32_t* pairs, int A, int cells, uint64_t h) {
     const int lane = threadIdx.x;
-    const uint8_t* obst = obst_all + (size_t)env * cells;
-    const uint32_t* lab = labels + (shared ? 0 : (size_t)local * cells);
-    uint32_t* pend = pending + (size_t)local * cells;
-    const uint64_t h = instance_hash(key_base + (uint64_t)env, epoch[env], attempt);
     const uint32_t budget = gen_candidate_budget((uint32_t)cells);
-    const uint32_t pad = ((uint32_t)r << 16) | (uint32_t)r;
     int placed = 0;
     uint32_t cur_root = NONE, cur_val = 0u;  // cached pending word (wave-uniform)
     for (uint32_t t0 = 0; t0 < budget && placed < A; t0 += 64) {
@@ -235,56 +180,27 @@ __global__ __launch_bounds__(64) void place_kernel(const uint8_t* __restrict__ o
             } else {
                 cur_val &= TAKEN;
                 if (lane == 0) {
-                    const uint32_t s = open - 1u;
-                    const size_t gi = (size_t)env * A + placed;
-                    const uint32_t pc = (((s / Wd) << 16) | (s % Wd)) + pad;
-                    const uint32_t tc = (((ck / Wd) << 16) | (ck % Wd)) + pad;
-                    pos[gi] = pc;
-                    pos0[gi] = pc;
-                    tgt[gi] = tc;
-                    tgt0[gi] = tc;
-                    active[gi] = 1;
-                    if (tcount) tcount[gi] = 0u;
+                    pairs[2 * placed] = open - 1u;
+                    pairs[2 * placed + 1] = ck;
                 }
                 ++placed;
             }
         }
     }
-    if (lane == 0) {
-        if (cur_root != NONE) st<false>(pend + cur_root, cur_val);
-        if (placed == A) {
-            todo[env] = 0;
-            elapsed[env] = 0;
-            macc[env] = make_int4(0, 0, 0, 0);
-        } else {
-            atomicAdd(fail_count, 1u);
-        }
-    }
+    return placed;
 }
 
-// Lifelong component tables of one environment per workgroup (stable counting sort of the free cells by
-// component): comp_begin/comp_len per cell, comp_cells = unpadded (x << 16) | y grouped by component in
-// order of the components' first cells, row-major inside.  `counters` (scratch, one word per cell) holds the
-// component sizes and then the fill pointers.  The parallel passes (clear, count, copy) use all four waves;
-// the two order-dependent passes (exclusive scan over the roots, stable fill) are walked by wave 0, four
-// 64-cell chunks per iteration so that four loads are in flight.  The LARGEST component (the giant one holds
-// ~95 % of the free cells at density 0.3) keeps its fill pointer in a register: no L2 round trip per chunk.
-__global__ __launch_bounds__(256) void tables_kernel(const uint8_t* __restrict__ obst_all,
-                                                     const uint32_t* __restrict__ labels, uint32_t* __restrict__ counters,
-                                                     const uint8_t* __restrict__ regen, uint32_t* __restrict__ comp_begin,
-                                                     uint32_t* __restrict__ comp_len, uint32_t* __restrict__ comp_cells,
-                                                     int env_begin, int Wd, int cells, int shared) {
-    const int local = blockIdx.x;
-    const int env = env_begin + local;
-    if (!regen[env]) return;
+// Lifelong component tables (stable counting sort of the free cells by component): comp_begin/comp_len per cell,
+// comp_cells = unpadded (x << 16) | y grouped by component in order of the components' first cells, row-major
+// inside.  `cnt` (scratch, one word per cell) holds the component sizes and then the fill pointers.  The parallel
+// passes (clear, count, copy) use all four waves; the two order-dependent passes (exclusive scan over the roots,
+// stable fill) are walked by wave 0, four 64-cell chunks per iteration so that four loads are in flight.  The
+// LARGEST component (the giant one holds ~95 % of the free cells at density 0.3) keeps its fill pointer in a
+// register: no L2 round trip per chunk.
+__device__ void tables_phase(const uint8_t* __restrict__ obst, const uint32_t* __restrict__ lab, uint32_t* __restrict__ cnt,
+                             uint32_t* __restrict__ cb, uint32_t* __restrict__ cl, uint32_t* __restrict__ cc, int Wd,
+                             int cells, uint32_t* s_big) {
     const int tid = threadIdx.x, lane = tid & 63;
-    const uint8_t* obst = obst_all + (size_t)env * cells;
-    const uint32_t* lab = labels + (shared ? 0 : (size_t)local * cells);
-    uint32_t* cnt = counters + (size_t)local * cells;
-    uint32_t* cb = comp_begin + (size_t)env * cells;
-    uint32_t* cl = comp_len + (size_t)env * cells;
-    uint32_t* cc = comp_cells + (size_t)env * cells;
-    __shared__ uint32_t s_big[2];  // root and first slot of the largest component
     for (int c = tid; c < cells; c += 256) st<false>(cnt + c, 0u);
     __syncthreads();
     for (int c = tid; c < cells; c += 256)
@@ -387,7 +303,123 @@ __global__ __launch_bounds__(256) void tables_kernel(const uint8_t* __restrict__
     }
 }
 
-// agent/target cells -> validity flags for explicitly given states are checked on the host (VecPogema); nothing here.
+// u8 map [H, W] -> this env's padded 1-bit-per-cell bitmap with the artificial border of SURVEY A1
+// (same layout as pack_obstacles_kernel in pgx_kernels.hip).
+__device__ void pack_phase(const uint8_t* __restrict__ obst, uint32_t* __restrict__ bm, int H, int Wd, int r, int wpr, int bmw) {
+    const int PH = H + 2 * r, PW = Wd + 2 * r;
+    for (int w = threadIdx.x; w < bmw; w += blockDim.x) {
+        const int x = w / wpr;
+        const int y0 = (w - x * wpr) * 32;
+        uint32_t bits = 0u;
+        const bool ring_row = (x == r - 1) || (x == PH - r);
+        const bool in_rows = (x >= r) && (x < PH - r);
+        for (int b = 0; b < 32; ++b) {
+            const int y = y0 + b;
+            if (y >= PW) break;
+            uint32_t v = 0u;
+            const bool span = (y >= r - 1) && (y <= PW - r);
+            if (ring_row && span) v = 1u;
+            else if (in_rows && (y == r - 1 || y == PW - r)) v = 1u;
+            else if (in_rows && y >= r && y < PW - r) v = obst[(x - r) * Wd + (y - r)] != 0 ? 1u : 0u;
+            bits |= v << b;
+        }
+        bm[w] = bits;
+    }
+}
+
+}  // namespace
+
+// todo/regen flags and generation counters for one reset call
+__global__ void reset_begin_kernel(const uint8_t* __restrict__ mask, uint8_t* __restrict__ todo,
+                                   uint8_t* __restrict__ regen, uint32_t* __restrict__ epoch, int batch) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const uint8_t m = mask ? (mask[b] != 0 ? 1 : 0) : 1;
+    todo[b] = m;
+    regen[b] = m;
+    epoch[b] = mask ? epoch[b] + m : 0u;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The reset kernel: one 256-thread workgroup builds one environment's instance from nothing.
+//   for attempt = 0 .. max_retries-1:   obstacles (hash per cell, or the given map) -> components -> placement
+//   on success: commit map, agents, targets, step counter, metric accumulators; pack the padded bitmap;
+//               lifelong: component tables.   on failure: the environment is left untouched and counted.
+// Everything an attempt produces lives in per-slot scratch (map bytes, labels, pending) and LDS (the pairs), so
+// a failed environment keeps its previous instance -- which is what lets pgx_regenerate run without a host sync.
+//   given_state != 0 (pgx_reset_from_state, lifelong): the map is already installed; only components + tables.
+// ------------------------------------------------------------------------------------------------
+template <bool LDS>
+__global__ __launch_bounds__(256) void reset_env_kernel(const ResetParams p) {
+    extern __shared__ uint32_t s_dyn[];
+    __shared__ uint32_t s_flag[4];
+    const int local = blockIdx.x;
+    const int env = p.env_begin + local;
+    if (!p.todo[env]) return;
+    const int tid = threadIdx.x;
+    const int cells = p.H * p.Wd;
+    uint32_t* forest = s_dyn;                               // [cells] when LDS
+    uint32_t* pairs = s_dyn + (LDS ? cells : 0);            // [2 * A]
+    uint32_t* lab = p.labels + (size_t)local * cells;
+    uint32_t* pend = p.pending + (size_t)local * cells;
+    uint8_t* env_map = p.map_u8 + (size_t)env * cells;
+    const uint8_t* obst = env_map;
+    if (!p.given_state) {
+        uint8_t* draft = p.scratch_map + (size_t)local * cells;
+        obst = draft;
+        const uint32_t epoch = p.epoch[env];
+        bool ok = false;
+        for (int attempt = 0; attempt < p.max_retries && !ok; ++attempt) {
+            const uint64_t h = instance_hash(p.key_base + (uint64_t)env, epoch, (uint32_t)attempt);
+            const bool redraw = !p.shared_map || attempt == 0;
+            for (int c = tid; c < cells; c += 256) {
+                if (redraw)
+                    draft[c] = p.shared_map ? (p.shared_map[c] != 0 ? 1 : 0)
+                                            : ((sm64(h ^ (GEN_TAG_OBST | (uint64_t)c)) >> 40) < p.thr ? 1 : 0);
+                st<false>(pend + c, 0u);
+            }
+            __syncthreads();
+            if (redraw) ccl_phase<LDS>(draft, lab, forest, p.H, p.Wd);
+            if (tid < 64) {
+                const int placed = place_phase(draft, lab, pend, pairs, p.A, cells, h);
+                if (tid == 0) s_flag[0] = placed == p.A ? 1u : 0u;
+            }
+            __syncthreads();
+            ok = s_flag[0] != 0u;
+            __syncthreads();
+        }
+        if (!ok) {
+            if (tid == 0) atomicAdd(p.fail_count, 1u);
+            return;
+        }
+        // ---- commit -------------------------------------------------------------------------------
+        for (int c = tid; c < cells; c += 256) env_map[c] = draft[c];
+        const uint32_t pad = ((uint32_t)p.r << 16) | (uint32_t)p.r;
+        for (int i = tid; i < p.A; i += 256) {
+            const uint32_t s = pairs[2 * i], t = pairs[2 * i + 1];
+            const size_t gi = (size_t)env * p.A + i;
+            const uint32_t pc = (((s / p.Wd) << 16) | (s % p.Wd)) + pad;
+            const uint32_t tc = (((t / p.Wd) << 16) | (t % p.Wd)) + pad;
+            p.pos[gi] = pc;
+            p.pos0[gi] = pc;
+            p.tgt[gi] = tc;
+            p.tgt0[gi] = tc;
+            p.active[gi] = 1;
+            if (p.tcount) p.tcount[gi] = 0u;
+        }
+        if (tid == 0) {
+            p.todo[env] = 0;
+            p.elapsed[env] = 0;
+            p.macc[env] = make_int4(0, 0, 0, 0);
+        }
+        pack_phase(draft, p.obst_bm + (size_t)env * p.bmw, p.H, p.Wd, p.r, p.wpr, p.bmw);
+    } else {
+        ccl_phase<LDS>(obst, lab, forest, p.H, p.Wd);
+    }
+    if (p.lifelong)
+        tables_phase(obst, lab, pend, p.comp_begin + (size_t)env * cells, p.comp_len + (size_t)env * cells,
+                     p.comp_cells + (size_t)env * cells, p.Wd, cells, s_flag + 2);
+}
 
 // ---- launchers --------------------------------------------------------------------------------------
 hipError_t launch_reset_begin(const uint8_t* mask, uint8_t* todo, uint8_t* regen, uint32_t* epoch, int batch,
@@ -396,49 +428,21 @@ hipError_t launch_reset_begin(const uint8_t* mask, uint8_t* todo, uint8_t* regen
     return hipGetLastError();
 }
 
-hipError_t launch_gen_obstacles(uint8_t* obst, const uint8_t* shared_map, const uint8_t* todo, const uint32_t* epoch,
-                                int env_begin, int env_count, int cells, uint32_t thr, uint64_t key_base,
-                                uint32_t attempt, hipStream_t s) {
-    const size_t total = (size_t)env_count * cells;
-    hipLaunchKernelGGL(gen_obstacles_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, obst, shared_map,
-                       todo, epoch, env_begin, env_count, cells, thr, key_base, attempt);
-    return hipGetLastError();
-}
+bool reset_forest_in_lds(int H, int Wd, int A) { return (size_t)H * Wd * 4 + (size_t)A * 8 <= 64 * 1024; }
 
-hipError_t launch_ccl(const uint8_t* obst, uint32_t* labels, uint32_t* pending, const uint8_t* todo, int env_begin,
-                      int env_count, int H, int Wd, int shared, hipStream_t s) {
-    const size_t forest_bytes = (size_t)H * Wd * sizeof(uint32_t);
-    if (forest_bytes <= 64 * 1024) {  // forest in LDS
-        if (forest_bytes > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ccl_kernel<true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)forest_bytes);
+hipError_t launch_reset_env(const ResetParams& p, hipStream_t s) {
+    const bool lds = reset_forest_in_lds(p.H, p.Wd, p.A);
+    const size_t dyn = (lds ? (size_t)p.H * p.Wd * 4 : 0) + (size_t)p.A * 8;
+    if (lds) {
+        if (dyn > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&reset_env_kernel<true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(ccl_kernel<true>, dim3(env_count), dim3(256), forest_bytes, s, obst, labels, pending, todo,
-                           env_begin, H, Wd, shared);
+        hipLaunchKernelGGL(reset_env_kernel<true>, dim3(p.env_count), dim3(256), dyn, s, p);
     } else {
-        hipLaunchKernelGGL(ccl_kernel<false>, dim3(env_count), dim3(256), 0, s, obst, labels, pending, todo, env_begin,
-                           H, Wd, shared);
+        hipLaunchKernelGGL(reset_env_kernel<false>, dim3(p.env_count), dim3(256), dyn, s, p);
     }
-    return hipGetLastError();
-}
-
-hipError_t launch_place(const uint8_t* obst, const uint32_t* labels, uint32_t* pending, uint8_t* todo,
-                        const uint32_t* epoch, uint32_t* pos, uint32_t* tgt, uint32_t* pos0, uint32_t* tgt0,
-                        uint8_t* active, uint32_t* tcount, int32_t* elapsed, int4* macc, uint32_t* fail_count,
-                        int env_begin, int env_count, int A, int Wd, int cells, int r, int shared, uint64_t key_base,
-                        uint32_t attempt, hipStream_t s) {
-    hipLaunchKernelGGL(place_kernel, dim3(env_count), dim3(64), 0, s, obst, labels, pending, todo, epoch,
-                       pos, tgt, pos0, tgt0, active, tcount, elapsed, macc, fail_count, env_begin, env_count, A, Wd,
-                       cells, r, shared, key_base, attempt);
-    return hipGetLastError();
-}
-
-hipError_t launch_tables(const uint8_t* obst, const uint32_t* labels, uint32_t* counters, const uint8_t* regen,
-                         uint32_t* comp_begin, uint32_t* comp_len, uint32_t* comp_cells, int env_begin, int env_count,
-                         int Wd, int cells, int shared, hipStream_t s) {
-    hipLaunchKernelGGL(tables_kernel, dim3(env_count), dim3(256), 0, s, obst, labels, counters, regen, comp_begin,
-                       comp_len, comp_cells, env_begin, Wd, cells, shared);
     return hipGetLastError();
 }
 

@@ -62,6 +62,12 @@ class VecPogema:
         self.env_index_base = int(env_index_base)
         if auto_reset is None:
             auto_reset = bool(gc.auto_reset) if gc.auto_reset is not None else False
+        # auto_reset=True: a finished env returns to its stored initial state inside step() (the reference's auto-reset
+        # wrapper with a fixed seed).  auto_reset="regenerate": it gets a NEW random instance instead (the wrapper with
+        # seed=None), drawn on the device right after the step kernel, no host round trip (pgx_regenerate).
+        self.regenerate = auto_reset == "regenerate"
+        if self.regenerate and (gc.observation_type != "default" or (gc.map is not None and gc.agents_xy is not None)):
+            raise NotImplementedError("auto_reset='regenerate' needs random instances and observation_type='default'")
         self.auto_reset = bool(auto_reset)
         self.reuse_buffers = bool(reuse_buffers)
         # float32 is the reference's observation dtype (gymnasium Box float32) and the default; torch.uint8 writes
@@ -80,6 +86,8 @@ class VecPogema:
         _lib.check(self._lib.pgx_create(C.byref(cfg), self.device_index, C.byref(self._handle)))
         self._bufs = None
         self._buf_i = 0
+        self._shared = None
+        self._reset_seed = None
         self._initial = None
         # episode metrics (fused metric wrappers): rows are refreshed on the step that ends an env's episode
         self.metrics = torch.zeros((self.batch, len(_lib.METRIC_NAMES)), dtype=torch.float32, device=self.device)
@@ -107,6 +115,10 @@ class VecPogema:
 
     def get_num_agents(self):
         return self.num_agents
+
+    def regenerate_failures(self) -> int:
+        """Envs that kept their previous instance because no fresh one could be placed (auto_reset='regenerate')."""
+        return int(self._lib.pgx_regenerate_failures(self._handle, self._stream()))
 
     # ------------------------------------------------------------------------------------------
     def generate(self, seed: Optional[int] = None):
@@ -241,7 +253,7 @@ class VecPogema:
         if gc.map is not None and gc.agents_xy is not None:
             raise NotImplementedError("reset_where draws random instances; this GridConfig fixes map and agents")
         if seed is None:
-            seed = getattr(self, "_reset_seed", None)
+            seed = self._reset_seed
         shared = self._shared_map_tensor()
         _lib.check(self._lib.pgx_reset_random(self._handle, float(gc.density), self._resolve_seed(seed),
                                               shared.data_ptr() if shared is not None else None, mask.data_ptr(), 10,
@@ -300,6 +312,15 @@ class VecPogema:
             self._handle, actions.data_ptr(), self._ACTION_CODE[actions.dtype],
             obs.data_ptr() if compute_obs else None, rewards.data_ptr(), terminated.data_ptr(),
             truncated.data_ptr(), is_active.data_ptr(), self._stream()))
+        if self.regenerate:
+            if self._reset_seed is None:
+                raise RuntimeError("auto_reset='regenerate' needs reset(seed) first (random instances)")
+            if self._shared is None and self.grid_config.map is not None:
+                self._shared = self._shared_map_tensor()
+            _lib.check(self._lib.pgx_regenerate(
+                self._handle, self.episode_done.data_ptr(), float(self.grid_config.density), self._reset_seed,
+                self._shared.data_ptr() if self._shared is not None else None, 3,
+                obs.data_ptr() if compute_obs else None, self._stream()))
         infos = {"is_active": is_active, "episode_done": self.episode_done, "metrics": self.metrics}
         return (self._wrap_obs(obs) if compute_obs else None), rewards, terminated, truncated, infos
 

@@ -164,3 +164,68 @@ def test_unplaceable_instances_raise():
         env.reset(seed=1)
     assert ei.value.code == -5
     env.close()
+
+
+@pytest.mark.parametrize("on_target", ["finish", "restart"])
+def test_regenerate_mode_tracks_oracle(on_target):
+    """auto_reset='regenerate' (pgx_regenerate, no host sync): a finished env continues on a NEW instance whose
+    generation counter advanced; everything is checked step by step against per-env Python oracles that are
+    rebuilt from the generator oracle at every episode end."""
+    from oracle.pogema_oracle import PogemaOracle
+    from pogema_amd import GridConfig, VecPogema
+    B, S, A, r, seed, base, T = 12, 10, 4, 2, 21, 7, 5
+    gc = GridConfig(size=S, num_agents=A, obs_radius=r, density=0.25, seed=seed, on_target=on_target,
+                    max_episode_steps=T, collision_system="priority")
+    env = VecPogema(gc, batch=B, env_index_base=base, auto_reset="regenerate")
+    obs, _ = env.reset(seed=seed)
+
+    def fresh(b, epoch):
+        o, a, t = G.generate_instance(0, seed + base + b, S, S, A, 0.25, epoch=epoch)
+        return PogemaOracle(o, a, t, obs_radius=r, collision_system="priority", on_target=on_target,
+                            max_episode_steps=T, auto_reset=False, seed=seed, env_index=base + b)
+
+    epochs = [0] * B
+    refs = [fresh(b, 0) for b in range(B)]
+    assert np.array_equal(obs.cpu().numpy(), np.stack([np.stack(e._obs()) for e in refs]))
+    rng = np.random.default_rng(5)
+    for t in range(3 * T + 2):
+        acts = rng.integers(0, 5, size=(B, A))
+        obs, rew, term, trunc, info = env.step(torch.from_numpy(acts).cuda())
+        st = env.get_state()
+        for b in range(B):
+            robs, rrew, rterm, rtrunc, rinfo = refs[b].step(acts[b])
+            assert rew[b].tolist() == rrew and term[b].tolist() == rterm and trunc[b].tolist() == rtrunc, (t, b)
+            done = all(rterm) or all(rtrunc)
+            assert bool(info["episode_done"][b]) == done
+            if done:
+                epochs[b] += 1
+                refs[b] = fresh(b, epochs[b])
+                robs = refs[b]._obs()
+            rs = refs[b].get_state()
+            assert np.array_equal(obs[b].cpu().numpy(), np.stack(robs)), (t, b)
+            assert np.array_equal(st["agents_xy"][b].cpu().numpy(), rs["agents_xy"])
+            assert np.array_equal(st["targets_xy"][b].cpu().numpy(), rs["targets_xy"])
+            assert int(st["elapsed"][b]) == rs["elapsed"] and st["is_active"][b].cpu().numpy().tolist() == rs["is_active"].astype(bool).tolist()
+    assert max(epochs) >= 3 and env.regenerate_failures() == 0
+    env.close()
+
+
+def test_regenerate_failure_keeps_previous_instance():
+    """When no fresh instance can be placed, the env falls back to its stored initial state (plain auto-reset)
+    and the failure is counted -- nothing is left half-written."""
+    from pogema_amd import GridConfig, VecPogema
+    m = np.ones((6, 6), np.uint8)
+    m[0, :4] = 0  # one corridor of 4 free cells: 2 agents fit exactly once ...
+    gc = GridConfig(map=m.tolist(), num_agents=2, obs_radius=2, seed=3, max_episode_steps=3)
+    env = VecPogema(gc, batch=5, auto_reset="regenerate")
+    env.reset(seed=3)
+    first = env.get_state()
+    env._shared = torch.ones((6, 6), dtype=torch.uint8, device="cuda")  # ... and from now on the "map" is full
+    for _ in range(3):
+        env.step(torch.zeros((5, 2), dtype=torch.int64, device="cuda"))
+    after = env.get_state()
+    assert env.regenerate_failures() == 5
+    assert torch.equal(after["agents_xy"], first["agents_xy"]) and torch.equal(after["targets_xy"], first["targets_xy"])
+    assert int(after["elapsed"].max()) == 0 and bool(after["is_active"].all())
+    assert np.array_equal(env._initial[0].cpu().numpy(), np.broadcast_to(m, (5, 6, 6)))
+    env.close()

@@ -63,7 +63,7 @@ def cpu_baseline(size, agents, r, collision, density, max_steps, target_seconds=
            np.empty((B, agents), np.uint8), np.empty((B, agents), np.uint8), np.empty((B, agents), np.uint8))
     env.step(pool[0], nthreads=1, out=out)  # touch pages
     # the host is often memory-bound on the observation write: pick the best thread count quickly
-    best, cores = 0.0, 1
+    best, cores, single = 0.0, 1, 0.0
     cands = sorted({1, 2, 4, 8, 16, 32, 64, avail // 2, avail} - {0})
     for nt in [c for c in cands if c <= avail]:
         tc = time.perf_counter()
@@ -72,6 +72,8 @@ def cpu_baseline(size, agents, r, collision, density, max_steps, target_seconds=
             env.step(pool[n % 16], nthreads=nt, out=out)
             n += 1
         rate = n / (time.perf_counter() - tc)
+        if nt == 1:
+            single = rate * B * agents
         if rate > best:
             best, cores = rate, nt
     steps = 0
@@ -84,6 +86,7 @@ def cpu_baseline(size, agents, r, collision, density, max_steps, target_seconds=
             break
     env.close()
     return {"value": B * agents * steps / dt, "unit": "agent-steps/s", "cores": cores, "kind": "port",
+            "single_core_value": single, "host_cores_available": avail,
             "sample": f"{B} envs x {agents} agents x {steps} steps of the same workload ({size}x{size}, r={r}, "
                       f"{collision}), plain-C oracle port with OpenMP over envs, {dt:.1f} s wall"}
 

@@ -44,9 +44,9 @@ except Exception:  # pragma: no cover - exercised only where gymnasium is missin
 
 
 class Pogema:
-    def __init__(self, grid_config: Optional[GridConfig] = None, device="cuda:0"):
+    def __init__(self, grid_config: Optional[GridConfig] = None, device="cuda:0", auto_reset=None):
         self.grid_config = grid_config if grid_config is not None else GridConfig(num_agents=2)
-        self._vec = VecPogema(self.grid_config, batch=1, device=device)
+        self._vec = VecPogema(self.grid_config, batch=1, device=device, auto_reset=auto_reset)
         full = 2 * self.grid_config.obs_radius + 1
         self.observation_space = _Box(0.0, 1.0, shape=(3, full, full), dtype=np.float32)
         self.action_space = _Discrete(len(self.grid_config.MOVES))
@@ -213,11 +213,60 @@ class PogemaParallel:
                 dict(zip(names, infos)))
 
 
+class PogemaSampleFactory(Pogema):
+    """`integration='SampleFactory'` view (upstream `pogema/integrations/sample_factory.py`: AutoResetWrapper over
+    IsMultiAgentWrapper over MetricsForwardingWrapper): multi-agent lists, auto-reset inside `step()` (done by the
+    engine), `is_multiagent` / `num_agents` attributes, episode metrics copied to `infos[i]['episode_extra_stats']`."""
+
+    is_multiagent = True
+
+    def __init__(self, grid_config: Optional[GridConfig] = None, device="cuda:0"):
+        super().__init__(grid_config, device=device, auto_reset=True)
+
+    @property
+    def num_agents(self):
+        return self.get_num_agents()
+
+    def step(self, action):
+        obs, rewards, terminated, truncated, infos = super().step(action)
+        for info in infos:
+            if "metrics" in info:
+                info["episode_extra_stats"] = dict(info["metrics"])
+        return obs, rewards, terminated, truncated, infos
+
+
+class PogemaSingleAgent:
+    """`integration='gymnasium'` view for `num_agents == 1` (upstream `SingleAgentWrapper`): plain gymnasium
+    signature with scalar reward / flags and one observation array."""
+
+    def __init__(self, grid_config: Optional[GridConfig] = None, device="cuda:0"):
+        self._env = Pogema(grid_config, device=device)
+        if self._env.get_num_agents() != 1:
+            raise ValueError("integration='gymnasium' is the single-agent view: num_agents must be 1")
+        self.observation_space, self.action_space = self._env.observation_space, self._env.action_space
+        self.grid_config = self._env.grid_config
+
+    def reset(self, seed: Optional[int] = None, options=None):
+        obs, infos = self._env.reset(seed=seed)
+        return obs[0], infos[0]
+
+    def step(self, action):
+        obs, rew, term, trunc, infos = self._env.step([int(action)])
+        return obs[0], rew[0], term[0], trunc[0], infos[0]
+
+    def close(self):
+        self._env.close()
+
+
 def pogema_v0(grid_config: Optional[GridConfig] = None, device="cuda:0"):
     """Factory with the reference's name: dispatches on `GridConfig.integration`."""
     gc = grid_config if grid_config is not None else GridConfig(num_agents=2)
-    if gc.integration in (None, "gymnasium"):
+    if gc.integration is None:
         return Pogema(gc, device=device)
+    if gc.integration == "gymnasium":
+        return PogemaSingleAgent(gc, device=device)
     if gc.integration == "PettingZoo":
         return PogemaParallel(gc, device=device)
+    if gc.integration == "SampleFactory":
+        return PogemaSampleFactory(gc, device=device)
     raise NotImplementedError(f"integration={gc.integration!r} is outside the hot-path scope of this build")

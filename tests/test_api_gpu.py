@@ -167,3 +167,30 @@ def test_list_api_state_accessors():
     assert full["elapsed"] == 3 and full["is_active"] == [bool(v) for v in st["is_active"]]
     assert env.get_targets_xy_relative() == [(int(x - sx), int(y - sy)) for (x, y), (sx, sy) in zip(rt, ra)]
     env.close()
+
+
+def test_integration_views():
+    """`GridConfig.integration` dispatch: single-agent gymnasium signature, SampleFactory-style auto-reset view."""
+    from pogema_amd import GridConfig, pogema_v0
+    env = pogema_v0(GridConfig(size=8, num_agents=1, obs_radius=2, density=0.2, seed=5, integration="gymnasium",
+                               max_episode_steps=4))
+    obs, info = env.reset(seed=5)
+    assert obs.shape == (3, 5, 5) and info == {"is_active": True}
+    trunc = False
+    for _ in range(4):
+        obs, rew, term, trunc, info = env.step(0)
+        assert isinstance(rew, float) and isinstance(term, bool)
+    assert trunc is True and "metrics" in info
+    env.close()
+    sf = pogema_v0(GridConfig(size=8, num_agents=3, obs_radius=2, density=0.2, seed=5, integration="SampleFactory",
+                              max_episode_steps=3))
+    assert sf.is_multiagent and sf.num_agents == 3
+    first, _ = sf.reset(seed=5)
+    for t in range(3):
+        obs, rew, term, trunc, infos = sf.step([0, 0, 0])
+    assert all(trunc) and "episode_extra_stats" in infos[0]
+    # auto-reset happened inside step(): the observation is the first observation of the (fixed-seed) instance
+    assert all(np.array_equal(a, b) for a, b in zip(obs, first))
+    sf.close()
+    with pytest.raises(NotImplementedError):
+        pogema_v0(GridConfig(num_agents=2, integration="PyMARL"))

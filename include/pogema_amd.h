@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PGX_ABI_VERSION 1
+#define PGX_ABI_VERSION 2
 
 /* error codes */
 #define PGX_OK 0
@@ -82,6 +82,11 @@ typedef struct pgx_config {
     uint64_t seed;             /* lifelong (restart) target stream seed                        */
     int64_t env_index_base;    /* global index of env 0 of this shard (keeps lifelong streams  */
                                /* independent of how the batch is sharded over devices)        */
+    int32_t random_outside;    /* 0: cells beyond the border ring are FREE (`empty_outside=True`, the     */
+                               /*    reference's default); 1: Bernoulli(outside_density) obstacles there  */
+                               /*    (`empty_outside=False`; the stream is this build's own, keyed by      */
+                               /*    seed, global env index and the env's generation counter)             */
+    float outside_density;
 } pgx_config;
 
 typedef struct pgx_env pgx_env; /* opaque */

@@ -19,7 +19,8 @@ class PoConfig(C.Structure):
     _fields_ = [("batch", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("num_agents", C.c_int32),
                 ("obs_radius", C.c_int32), ("collision_system", C.c_int32), ("on_target", C.c_int32),
                 ("max_episode_steps", C.c_int32), ("auto_reset", C.c_int32), ("reserved0", C.c_int32),
-                ("seed", C.c_uint64), ("env_index_base", C.c_int64)]
+                ("seed", C.c_uint64), ("env_index_base", C.c_int64), ("random_outside", C.c_int32),
+                ("outside_density", C.c_float)]
 
 
 _lib = None
@@ -50,12 +51,14 @@ class COracle:
     """Batched CPU oracle with the same surface as the engine (numpy in / numpy out)."""
 
     def __init__(self, batch, height, width, num_agents, obs_radius, collision_system="priority", on_target="finish",
-                 max_episode_steps=64, auto_reset=False, seed=0, env_index_base=0):
+                 max_episode_steps=64, auto_reset=False, seed=0, env_index_base=0, empty_outside=True,
+                 outside_density=0.0):
         self.lib = load()
         self.B, self.H, self.Wd, self.A, self.r = batch, height, width, num_agents, obs_radius
         self.W = 2 * obs_radius + 1
         cfg = PoConfig(batch, height, width, num_agents, obs_radius, COLLISION[collision_system], ON_TARGET[on_target],
-                       max_episode_steps, int(auto_reset), 0, seed, env_index_base)
+                       max_episode_steps, int(auto_reset), 0, seed, env_index_base, 0 if empty_outside else 1,
+                       float(outside_density))
         self.h = self.lib.po_create(C.byref(cfg))
         if not self.h:
             raise MemoryError("po_create failed")

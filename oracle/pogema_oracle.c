@@ -29,6 +29,8 @@ typedef struct po_config {
     int32_t max_episode_steps, auto_reset, reserved0;
     uint64_t seed;
     int64_t env_index_base;
+    int32_t random_outside;   /* empty_outside=False: Bernoulli(outside_density) obstacles beyond the ring */
+    float outside_density;
 } po_config;
 
 typedef struct po_env {
@@ -171,6 +173,18 @@ int po_reset(po_env* e, const uint8_t* obstacles, const int32_t* agent_xy, const
     for (int b = 0; b < B; ++b) {
         uint8_t* o = e->obst + (size_t)b * P;
         memset(o, 0, P);
+        if (e->c.random_outside) { /* docs/SPEC.md S1: generation 0 (explicit states) */
+            double thr_d = (double)e->c.outside_density * 16777216.0 + 0.5;
+            if (thr_d < 0) thr_d = 0;
+            if (thr_d > 16777216.0) thr_d = 16777216.0;
+            const uint32_t thr = (uint32_t)thr_d;
+            const uint64_t h = splitmix64(splitmix64(splitmix64(e->c.seed) ^ (uint64_t)(e->c.env_index_base + b)) ^
+                                          (0x4F55545300000000ull | 0u));
+            for (int x = 0; x < PH; ++x)
+                for (int y = 0; y < PW; ++y)
+                    if (x < r - 1 || x > PH - r || y < r - 1 || y > PW - r)
+                        o[(size_t)x * PW + y] = (splitmix64(h ^ (uint64_t)(x * PW + y)) >> 40) < thr ? 1 : 0;
+        }
         for (int y = r - 1; y <= PW - r; ++y) { o[(size_t)(r - 1) * PW + y] = 1; o[(size_t)(PH - r) * PW + y] = 1; }
         for (int x = r - 1; x <= PH - r; ++x) { o[(size_t)x * PW + (r - 1)] = 1; o[(size_t)x * PW + (PW - r)] = 1; }
         for (int x = 0; x < H; ++x)

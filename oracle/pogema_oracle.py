@@ -32,6 +32,7 @@ COLLISION_SYSTEMS = ("priority", "block_both", "soft")
 ON_TARGET = ("finish", "restart", "nothing")
 
 _MASK32 = 0xFFFFFFFF
+TAG_OUTSIDE = 0x4F55545300000000  # 'OUTS'
 _MASK64 = 0xFFFFFFFFFFFFFFFF
 
 
@@ -88,19 +89,29 @@ def label_components(obstacles: np.ndarray):
 class Grid:
     """SURVEY A1/A2/A9/A10/A11 (upstream `pogema/grid.py: Grid`)."""
 
-    def __init__(self, obstacles, agents_xy, targets_xy, obs_radius, empty_outside=True):
+    def __init__(self, obstacles, agents_xy, targets_xy, obs_radius, empty_outside=True, outside=None):
         obstacles = np.asarray(obstacles)
         assert obstacles.ndim == 2
         self.r = int(obs_radius)
         self.map_h, self.map_w = obstacles.shape
         self.num_agents = len(agents_xy)
         assert len(targets_xy) == self.num_agents
-        assert empty_outside, "empty_outside=False draws from the reference RNG; not restated"
         self._raw_obstacles = obstacles.astype(np.int32)
         # --- add_artificial_border (A1): pad by r, wall ring at offset r-1, outside FREE -------
         r = self.r
         filled = np.zeros((self.map_h + 2 * r, self.map_w + 2 * r), dtype=np.int32)
         height, width = filled.shape
+        if not empty_outside:
+            # upstream: `rnd.binomial(1, density, padded shape)` from the grid's numpy generator (not reproducible);
+            # the build's own stream (docs/SPEC.md S1): a pure function of (seed, global env, generation, cell)
+            seed, env_index, epoch, density = outside
+            thr = int(np.floor(float(np.float32(density)) * 16777216.0 + 0.5))
+            h = splitmix64(splitmix64(splitmix64(seed & _MASK64) ^ (env_index & _MASK64)) ^ (TAG_OUTSIDE | (epoch & _MASK32)))
+            for px in range(height):
+                for py in range(width):
+                    if (splitmix64(h ^ (px * width + py)) >> 40) < thr:
+                        filled[px, py] = OBSTACLE
+            filled[r - 1:height - r + 1, r - 1:width - r + 1] = FREE
         filled[r - 1, r - 1:width - r + 1] = OBSTACLE
         filled[r - 1:height - r + 1, r - 1] = OBSTACLE
         filled[height - r, r - 1:width - r + 1] = OBSTACLE
@@ -180,7 +191,8 @@ class PogemaOracle:
     """
 
     def __init__(self, obstacles, agents_xy, targets_xy, obs_radius=5, collision_system="priority",
-                 on_target="finish", max_episode_steps=64, auto_reset=False, seed=0, env_index=0):
+                 on_target="finish", max_episode_steps=64, auto_reset=False, seed=0, env_index=0,
+                 empty_outside=True, outside_density=0.0, epoch=0):
         assert collision_system in COLLISION_SYSTEMS and on_target in ON_TARGET
         self._init_args = (np.array(obstacles, copy=True), [tuple(map(int, p)) for p in agents_xy],
                            [tuple(map(int, p)) for p in targets_xy])
@@ -191,6 +203,8 @@ class PogemaOracle:
         self.auto_reset = bool(auto_reset)
         self.seed = int(seed)
         self.env_index = int(env_index)
+        self.empty_outside = bool(empty_outside)
+        self._outside = (self.seed, self.env_index, int(epoch), float(outside_density))
         self.num_agents = len(agents_xy)
         self.reset()
 
@@ -206,7 +220,8 @@ class PogemaOracle:
     def reset(self):
         self._reset_metrics()
         obstacles, agents_xy, targets_xy = self._init_args
-        self.grid = Grid(obstacles, agents_xy, targets_xy, self.obs_radius)
+        self.grid = Grid(obstacles, agents_xy, targets_xy, self.obs_radius, empty_outside=self.empty_outside,
+                         outside=self._outside)
         self._elapsed_steps = 0
         if self.on_target == "restart":
             labels, pts = label_components(np.asarray(obstacles))

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PGX_LIB: diagnostic override (A/B of two builds of the SAME engine on one box); never a fallback
 LIB_PATH = os.environ.get("PGX_LIB") or os.path.join(_HERE, "libpogema_amd.so")
 
-PGX_ABI_VERSION = 1
+PGX_ABI_VERSION = 2
 
 COLLISION_SYSTEMS = {"priority": 0, "block_both": 1, "soft": 2}
 ON_TARGET = {"finish": 0, "restart": 1, "nothing": 2}
@@ -60,6 +60,7 @@ class PgxConfig(C.Structure):
         ("obs_radius", C.c_int32), ("collision_system", C.c_int32), ("on_target", C.c_int32),
         ("max_episode_steps", C.c_int32), ("auto_reset", C.c_int32), ("obs_dtype", C.c_int32),
         ("seed", C.c_uint64), ("env_index_base", C.c_int64),
+        ("random_outside", C.c_int32), ("outside_density", C.c_float),
     ]
 
 

@@ -113,6 +113,8 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
     if (cfg->collision_system < 0 || cfg->collision_system > 2)
         return fail(PGX_E_INVALID, "unknown collision_system %d", cfg->collision_system);
     if (cfg->on_target < 0 || cfg->on_target > 2) return fail(PGX_E_INVALID, "unknown on_target %d", cfg->on_target);
+    if (cfg->random_outside && !(cfg->outside_density >= 0.0f && cfg->outside_density <= 1.0f))
+        return fail(PGX_E_INVALID, "outside_density %.3f outside [0, 1]", (double)cfg->outside_density);
     if (cfg->obs_dtype != PGX_OBS_F32 && cfg->obs_dtype != PGX_OBS_U8)
         return fail(PGX_E_INVALID, "unknown obs_dtype %d", cfg->obs_dtype);
     if ((int64_t)cfg->num_agents > (int64_t)cfg->height * cfg->width)
@@ -250,6 +252,16 @@ static int ensure_reset_scratch(pgx_env* e, bool full) {
     return PGX_OK;
 }
 
+static pgx::OutsideParams outside_params(const pgx_env* e) {
+    pgx::OutsideParams o;
+    o.enabled = e->cfg.random_outside ? 1 : 0;
+    o.thr = pgx::gen_density_threshold(e->cfg.outside_density);
+    o.seed = e->cfg.seed;
+    o.env_index_base = e->cfg.env_index_base;
+    o.epoch = e->epoch;
+    return o;
+}
+
 static pgx::ResetParams reset_params(const pgx_env* e) {
     const pgx_config& c = e->cfg;
     pgx::ResetParams p;
@@ -263,6 +275,7 @@ static pgx::ResetParams reset_params(const pgx_env* e) {
     p.elapsed = e->elapsed; p.macc = e->macc;
     p.comp_begin = e->comp_begin; p.comp_len = e->comp_len; p.comp_cells = e->comp_cells;
     p.fail_count = e->fail_count;
+    p.outside = outside_params(e);
     return p;
 }
 
@@ -278,7 +291,7 @@ int pgx_reset_from_state(pgx_env* e, const uint8_t* obstacles, const int32_t* ag
     PGX_HIP(hipMemcpyAsync(e->map_u8, obstacles, B * cells, hipMemcpyDeviceToDevice, s));
     PGX_HIP(pgx::launch_reset_begin(nullptr, e->todo, e->regen, e->epoch, c.batch, s));
     PGX_HIP(pgx::launch_pack_obstacles(e->map_u8, nullptr, e->obst, c.batch, c.height, c.width, c.obs_radius, e->wpr,
-                                       e->bmw, s));
+                                       e->bmw, outside_params(e), s));
     PGX_HIP(pgx::launch_pack_agents(agent_xy, target_xy, e->pos, e->tgt, e->pos0, e->tgt0, e->active, e->tcount, BA,
                                     c.obs_radius, s));
     PGX_HIP(pgx::launch_zero_i32(e->elapsed, B, s));

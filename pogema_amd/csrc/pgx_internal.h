@@ -21,6 +21,32 @@ inline uint32_t gen_density_threshold(float density) {      // obstacle <=> 24 h
 }
 __host__ __device__ inline uint32_t gen_candidate_budget(uint32_t cells) { return 32u * cells + 64u; }
 
+// `empty_outside=False`: obstacles beyond the border ring, a pure function of (seed, global env, generation, cell)
+constexpr uint64_t GEN_TAG_OUTSIDE = 0x4F55545300000000ull;  // 'OUTS'
+struct OutsideParams {
+    int32_t enabled;
+    uint32_t thr;            // obstacle <=> 24 hash bits < thr
+    uint64_t seed;
+    int64_t env_index_base;
+    const uint32_t* epoch;   // [B] generation counters
+};
+__host__ __device__ inline uint64_t gen_sm64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// is padded cell (x, y) beyond the ring? (the ring itself and the map interior are never "outside")
+__host__ __device__ inline bool gen_is_outside(int x, int y, int PH, int PW, int r) {
+    return x < r - 1 || x > PH - r || y < r - 1 || y > PW - r;
+}
+__host__ __device__ inline uint64_t gen_outside_hash(uint64_t seed, uint64_t env_global, uint32_t epoch) {
+    return gen_sm64(gen_sm64(gen_sm64(seed) ^ env_global) ^ (GEN_TAG_OUTSIDE | epoch));
+}
+__host__ __device__ inline uint32_t gen_outside_bit(uint64_t h, int x, int y, int PW, uint32_t thr) {
+    return (gen_sm64(h ^ (uint64_t)(x * PW + y)) >> 40) < thr ? 1u : 0u;
+}
+
 // Kernel argument block of the step kernel (passed by value: lands in SGPRs / kernarg segment).
 struct StepParams {
     // geometry
@@ -80,7 +106,7 @@ hipError_t launch_step(const StepParams& p, const StepGeometry& g, hipStream_t s
 
 // `only` (device u8 [batch], may be null): pack just the flagged environments
 hipError_t launch_pack_obstacles(const uint8_t* obstacles, const uint8_t* only, uint32_t* bm, int batch, int H, int Wd,
-                                 int r, int wpr, int bmw, hipStream_t stream);
+                                 int r, int wpr, int bmw, const OutsideParams& outside, hipStream_t stream);
 
 // ---- on-device reset (pgx_reset.hip) ----------------------------------------------------------------
 // Kernel argument block of reset_env_kernel: one workgroup per environment of [env_begin, env_begin + env_count),
@@ -108,6 +134,7 @@ struct ResetParams {
     int4* macc;
     uint32_t *comp_begin, *comp_len, *comp_cells;  // lifelong only
     uint32_t* fail_count;       // envs that could not be filled
+    OutsideParams outside;      // `empty_outside=False`
 };
 hipError_t launch_reset_begin(const uint8_t* mask, uint8_t* todo, uint8_t* regen, uint32_t* epoch, int batch,
                               hipStream_t s);

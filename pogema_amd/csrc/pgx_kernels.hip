@@ -689,7 +689,8 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
 // u8 [B,H,W] obstacles -> padded 1-bit-per-cell bitmap with the artificial border of SURVEY A1:
 // padding r, OBSTACLE ring at offset r-1 (and at r+H / r+W), FREE outside.
 __global__ void pack_obstacles_kernel(const uint8_t* __restrict__ obstacles, const uint8_t* __restrict__ only,
-                                      uint32_t* __restrict__ bm, int batch, int H, int Wd, int r, int wpr, int bmw) {
+                                      uint32_t* __restrict__ bm, int batch, int H, int Wd, int r, int wpr, int bmw,
+                                      const OutsideParams outside) {
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)batch * bmw;
     if (gid >= total) return;
@@ -702,6 +703,9 @@ __global__ void pack_obstacles_kernel(const uint8_t* __restrict__ obstacles, con
     uint32_t bits = 0u;
     const bool ring_row = (x == r - 1) || (x == PH - r);
     const bool in_rows = (x >= r) && (x < PH - r);
+    uint64_t h_out = 0;
+    if (outside.enabled)
+        h_out = gen_outside_hash(outside.seed, (uint64_t)(outside.env_index_base + env), outside.epoch[env]);
     for (int b = 0; b < 32; ++b) {
         const int y = y0 + b;
         if (y >= PW) break;
@@ -711,6 +715,8 @@ __global__ void pack_obstacles_kernel(const uint8_t* __restrict__ obstacles, con
         else if (in_rows && (y == r - 1 || y == PW - r)) v = 1u;
         else if (in_rows && y >= r && y < PW - r)
             v = obstacles[((size_t)env * H + (x - r)) * Wd + (y - r)] != 0 ? 1u : 0u;
+        else if (outside.enabled && gen_is_outside(x, y, PH, PW, r))
+            v = gen_outside_bit(h_out, x, y, PW, outside.thr);
         bits |= v << b;
     }
     bm[gid] = bits;
@@ -838,11 +844,11 @@ hipError_t launch_step(const StepParams& p, const StepGeometry& g, hipStream_t s
 }
 
 hipError_t launch_pack_obstacles(const uint8_t* obstacles, const uint8_t* only, uint32_t* bm, int batch, int H, int Wd,
-                                 int r, int wpr, int bmw, hipStream_t stream) {
+                                 int r, int wpr, int bmw, const OutsideParams& outside, hipStream_t stream) {
     const size_t total = (size_t)batch * bmw;
     const int bs = 256;
     hipLaunchKernelGGL(pack_obstacles_kernel, dim3((unsigned)((total + bs - 1) / bs)), dim3(bs), 0, stream,
-                       obstacles, only, bm, batch, H, Wd, r, wpr, bmw);
+                       obstacles, only, bm, batch, H, Wd, r, wpr, bmw, outside);
     return hipGetLastError();
 }
 

@@ -305,8 +305,12 @@ __device__ void tables_phase(const uint8_t* __restrict__ obst, const uint32_t* _
 
 // u8 map [H, W] -> this env's padded 1-bit-per-cell bitmap with the artificial border of SURVEY A1
 // (same layout as pack_obstacles_kernel in pgx_kernels.hip).
-__device__ void pack_phase(const uint8_t* __restrict__ obst, uint32_t* __restrict__ bm, int H, int Wd, int r, int wpr, int bmw) {
+__device__ void pack_phase(const uint8_t* __restrict__ obst, uint32_t* __restrict__ bm, int H, int Wd, int r, int wpr, int bmw,
+                           const OutsideParams& outside, int env) {
     const int PH = H + 2 * r, PW = Wd + 2 * r;
+    uint64_t h_out = 0;
+    if (outside.enabled)
+        h_out = gen_outside_hash(outside.seed, (uint64_t)(outside.env_index_base + env), outside.epoch[env]);
     for (int w = threadIdx.x; w < bmw; w += blockDim.x) {
         const int x = w / wpr;
         const int y0 = (w - x * wpr) * 32;
@@ -321,6 +325,7 @@ __device__ void pack_phase(const uint8_t* __restrict__ obst, uint32_t* __restric
             if (ring_row && span) v = 1u;
             else if (in_rows && (y == r - 1 || y == PW - r)) v = 1u;
             else if (in_rows && y >= r && y < PW - r) v = obst[(x - r) * Wd + (y - r)] != 0 ? 1u : 0u;
+            else if (outside.enabled && gen_is_outside(x, y, PH, PW, r)) v = gen_outside_bit(h_out, x, y, PW, outside.thr);
             bits |= v << b;
         }
         bm[w] = bits;
@@ -412,7 +417,7 @@ __global__ __launch_bounds__(256) void reset_env_kernel(const ResetParams p) {
             p.elapsed[env] = 0;
             p.macc[env] = make_int4(0, 0, 0, 0);
         }
-        pack_phase(draft, p.obst_bm + (size_t)env * p.bmw, p.H, p.Wd, p.r, p.wpr, p.bmw);
+        pack_phase(draft, p.obst_bm + (size_t)env * p.bmw, p.H, p.Wd, p.r, p.wpr, p.bmw, p.outside, env);
     } else {
         ccl_phase<LDS>(obst, lab, forest, p.H, p.Wd);
     }

@@ -42,8 +42,6 @@ class VecPogema:
         self.grid_config = grid_config if grid_config is not None else GridConfig(num_agents=2)
         gc = self.grid_config
         self.observation_type = gc.observation_type  # 'default' tensor, or 'POMAPF' / 'MAPF' dict views
-        if not gc.empty_outside:
-            raise NotImplementedError("empty_outside=False draws from the reference's RNG; not implemented")
         if gc.possible_agents_xy is not None or gc.possible_targets_xy is not None:
             raise NotImplementedError("possible_agents_xy / possible_targets_xy are not supported by the engine's generator")
         if gc.persistent:
@@ -81,7 +79,8 @@ class VecPogema:
             obs_radius=self.obs_radius, collision_system=_lib.COLLISION_SYSTEMS[gc.collision_system],
             on_target=_lib.ON_TARGET[gc.on_target], max_episode_steps=int(gc.max_episode_steps),
             auto_reset=int(self.auto_reset), obs_dtype=_lib.OBS_DTYPES[self.obs_dtype], seed=int(gc.seed or 0),
-            env_index_base=self.env_index_base)
+            env_index_base=self.env_index_base, random_outside=0 if gc.empty_outside else 1,
+            outside_density=float(gc.density))
         self._handle = C.c_void_p()
         _lib.check(self._lib.pgx_create(C.byref(cfg), self.device_index, C.byref(self._handle)))
         self._bufs = None

@@ -30,9 +30,10 @@ def test_abi_version(engine_lib):
 
 
 def test_config_struct_layout():
-    # must match `struct pgx_config` in the header: 10 x int32, uint64, int64
-    assert C.sizeof(_lib.PgxConfig) == 10 * 4 + 8 + 8
+    # must match `struct pgx_config` in the header: 10 x int32, uint64, int64, int32, float
+    assert C.sizeof(_lib.PgxConfig) == 10 * 4 + 8 + 8 + 4 + 4
     assert _lib.PgxConfig.seed.offset == 40 and _lib.PgxConfig.env_index_base.offset == 48
+    assert _lib.PgxConfig.random_outside.offset == 56 and _lib.PgxConfig.outside_density.offset == 60
 
 
 @pytest.mark.parametrize("field,value,needle", [

@@ -102,3 +102,21 @@ def test_observation_planes_by_hand():
     env1 = PogemaOracle(obstacles, [(2, 2)], [(0, 0)], obs_radius=1)
     t = env1._obs()[0][2]
     assert t[0, 0] == 1 and t.sum() == 1
+
+
+@pytest.mark.parametrize("r", [1, 3, 6])
+def test_random_outside_c_port_equals_python(r):
+    """`empty_outside=False`: Bernoulli obstacles beyond the border ring (build-defined stream, docs/SPEC.md S1)."""
+    B, H, Wd, A = 3, 7, 9, 5
+    obstacles, agents, targets = generate_instances(B, H, Wd, A, 0.2, 31)
+    actions = random_actions(8, B, A, 2)
+    kw = dict(obs_radius=r, collision_system="soft", on_target="finish", max_episode_steps=5, auto_reset=True, seed=77,
+              env_index_base=3, empty_outside=False)
+    ref = oracle_rollout(obstacles, agents, targets, actions, **kw)
+    got = c_oracle_rollout(obstacles, agents, targets, actions, **kw)
+    assert_rollouts_equal(ref, got, f"random outside r={r}")
+    plain = oracle_rollout(obstacles, agents, targets, actions, **{**kw, "empty_outside": True})
+    if r > 1:
+        assert not np.array_equal(plain["obs0"][:, :, 0], ref["obs0"][:, :, 0]), "the outside must be visible somewhere"
+    # the ring and the map interior are never touched, so the dynamics are identical
+    assert np.array_equal(plain["agents_xy"], ref["agents_xy"])

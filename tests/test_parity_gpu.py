@@ -93,3 +93,17 @@ def test_uint8_observations(geom):
     ref = oracle_rollout(obstacles, agents, targets, actions, **kw)
     got = engine_rollout(obstacles, agents, targets, actions, obs_dtype=torch.uint8, **kw)
     assert_rollouts_equal(ref, got, f"u8/{name}")
+
+
+@pytest.mark.parametrize("geom", [g for g in GEOMETRIES if g[0] in ("baseline_cfg1", "odd_agents", "two_slots", "max_radius")],
+                         ids=lambda g: g[0])
+def test_random_outside(geom):
+    """`GridConfig(empty_outside=False)`: obstacles beyond the border ring, identical in engine and oracle."""
+    name, B, H, Wd, A, r, density, T, max_steps = geom
+    obstacles, agents, targets = generate_instances(B, H, Wd, A, density, 4242)
+    actions = random_actions(T, B, A, 7)
+    kw = dict(obs_radius=r, collision_system="priority", on_target="finish", max_episode_steps=max_steps, auto_reset=True,
+              seed=99, env_index_base=11, empty_outside=False)
+    ref = oracle_rollout(obstacles, agents, targets, actions, **kw)
+    got = engine_rollout(obstacles, agents, targets, actions, **kw)
+    assert_rollouts_equal(ref, got, f"random outside/{name}")

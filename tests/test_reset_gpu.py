@@ -166,8 +166,8 @@ def test_unplaceable_instances_raise():
     env.close()
 
 
-@pytest.mark.parametrize("on_target", ["finish", "restart"])
-def test_regenerate_mode_tracks_oracle(on_target):
+@pytest.mark.parametrize("on_target,empty_outside", [("finish", True), ("restart", True), ("finish", False)])
+def test_regenerate_mode_tracks_oracle(on_target, empty_outside):
     """auto_reset='regenerate' (pgx_regenerate, no host sync): a finished env continues on a NEW instance whose
     generation counter advanced; everything is checked step by step against per-env Python oracles that are
     rebuilt from the generator oracle at every episode end."""
@@ -175,14 +175,15 @@ def test_regenerate_mode_tracks_oracle(on_target):
     from pogema_amd import GridConfig, VecPogema
     B, S, A, r, seed, base, T = 12, 10, 4, 2, 21, 7, 5
     gc = GridConfig(size=S, num_agents=A, obs_radius=r, density=0.25, seed=seed, on_target=on_target,
-                    max_episode_steps=T, collision_system="priority")
+                    max_episode_steps=T, collision_system="priority", empty_outside=empty_outside)
     env = VecPogema(gc, batch=B, env_index_base=base, auto_reset="regenerate")
     obs, _ = env.reset(seed=seed)
 
     def fresh(b, epoch):
         o, a, t = G.generate_instance(0, seed + base + b, S, S, A, 0.25, epoch=epoch)
         return PogemaOracle(o, a, t, obs_radius=r, collision_system="priority", on_target=on_target,
-                            max_episode_steps=T, auto_reset=False, seed=seed, env_index=base + b)
+                            max_episode_steps=T, auto_reset=False, seed=seed, env_index=base + b,
+                            empty_outside=empty_outside, outside_density=0.25, epoch=epoch)
 
     epochs = [0] * B
     refs = [fresh(b, 0) for b in range(B)]

@@ -34,15 +34,23 @@ def random_actions(steps, batch, num_agents, seed, p_noop=0.2):
     return a.astype(np.int64)
 
 
+def outside_density_of(obstacles):
+    """`GridConfig.density` as the engine sees it for an explicit map: the obstacle fraction of env 0's map
+    (what `empty_outside=False` uses beyond the border ring)."""
+    m = np.asarray(obstacles[0])
+    return float(sum(1 for v in m.reshape(-1) if v != 0) / m.size)
+
+
 def oracle_rollout(obstacles, agents, targets, actions, *, obs_radius, collision_system, on_target,
-                   max_episode_steps, auto_reset, seed=0, env_index_base=0):
+                   max_episode_steps, auto_reset, seed=0, env_index_base=0, empty_outside=True):
     """Returns dict of arrays [T, B, ...] from the pure-Python oracle."""
     T, B, A = actions.shape
     W = 2 * obs_radius + 1
     envs = [PogemaOracle(obstacles[b], agents[b], targets[b], obs_radius=obs_radius,
                          collision_system=collision_system, on_target=on_target,
                          max_episode_steps=max_episode_steps, auto_reset=auto_reset, seed=seed,
-                         env_index=env_index_base + b) for b in range(B)]
+                         env_index=env_index_base + b, empty_outside=empty_outside,
+                         outside_density=outside_density_of(obstacles)) for b in range(B)]
     out = {
         "obs0": np.stack([np.stack(e._obs()) for e in envs]),
         "obs": np.zeros((T, B, A, 3, W, W), np.float32), "rewards": np.zeros((T, B, A), np.float32),
@@ -71,14 +79,14 @@ def oracle_rollout(obstacles, agents, targets, actions, *, obs_radius, collision
 
 
 def c_oracle_rollout(obstacles, agents, targets, actions, *, obs_radius, collision_system, on_target,
-                     max_episode_steps, auto_reset, seed=0, env_index_base=0, nthreads=1):
+                     max_episode_steps, auto_reset, seed=0, env_index_base=0, nthreads=1, empty_outside=True):
     """Same rollout through the plain-C oracle port (oracle/libpogema_oracle.so)."""
     from oracle.c_oracle import COracle
     T, B, A = actions.shape
     H, Wd = obstacles.shape[1:]
     W = 2 * obs_radius + 1
     env = COracle(B, H, Wd, A, obs_radius, collision_system, on_target, max_episode_steps, auto_reset, seed,
-                  env_index_base)
+                  env_index_base, empty_outside=empty_outside, outside_density=outside_density_of(obstacles))
     out = {
         "obs0": env.reset(obstacles, agents, targets),
         "obs": np.zeros((T, B, A, 3, W, W), np.float32), "rewards": np.zeros((T, B, A), np.float32),
@@ -101,7 +109,7 @@ def c_oracle_rollout(obstacles, agents, targets, actions, *, obs_radius, collisi
 
 def engine_rollout(obstacles, agents, targets, actions, *, obs_radius, collision_system, on_target,
                    max_episode_steps, auto_reset, seed=0, env_index_base=0, action_dtype="int64",
-                   device="cuda:0", obs_dtype=None):
+                   device="cuda:0", obs_dtype=None, empty_outside=True):
     """Same rollout through the HIP engine (C-ABI via pogema_amd.VecPogema)."""
     import torch
     from pogema_amd import GridConfig, VecPogema
@@ -109,7 +117,7 @@ def engine_rollout(obstacles, agents, targets, actions, *, obs_radius, collision
     H, Wd = obstacles.shape[1:]
     gc = GridConfig(map=obstacles[0].tolist(), num_agents=A, obs_radius=obs_radius,
                     collision_system=collision_system, on_target=on_target, max_episode_steps=max_episode_steps,
-                    seed=seed)
+                    seed=seed, empty_outside=empty_outside)
     extra = {} if obs_dtype is None else {"obs_dtype": obs_dtype}
     env = VecPogema(gc, batch=B, device=device, auto_reset=auto_reset, env_index_base=env_index_base, **extra)
     obs0 = env.reset_from_state(obstacles, agents, targets)

@@ -122,3 +122,28 @@ def generate_batch(seed, batch, height, width, num_agents, density, env_index_ba
     out = [generate_instance(seed, env_index_base + b, height, width, num_agents, density, epoch, max_retries, given_map)
            for b in range(batch)]
     return (np.stack([o[0] for o in out]), np.stack([o[1] for o in out]), np.stack([o[2] for o in out]))
+
+
+TAG_POSSIBLE_AGENTS = 0x5041475400000000   # 'PAGT'
+TAG_POSSIBLE_TARGETS = 0x5054475400000000  # 'PTGT'
+
+
+def place_from_possible(seed, env, possible_agents_xy, possible_targets_xy, num_agents, epoch=0):
+    """`GridConfig.possible_agents_xy / possible_targets_xy` (upstream `generate_from_possible_positions`: shuffle
+    both lists, take the first num_agents of each -- numpy stream, not reproducible).  Build-defined: the first
+    `num_agents` DISTINCT entries of the candidate stream idx_t = hash(h, tag, t) scaled to the list length."""
+    if len(possible_agents_xy) < num_agents or len(possible_targets_xy) < num_agents:
+        raise OverflowError("not enough possible positions")
+    h = instance_hash(seed, env, epoch, 0)
+    out = []
+    for tag, cells in ((TAG_POSSIBLE_AGENTS, possible_agents_xy), (TAG_POSSIBLE_TARGETS, possible_targets_xy)):
+        n, chosen, t = len(cells), [], 0
+        while len(chosen) < num_agents:
+            if t >= 32 * n + 64:
+                raise OverflowError("candidate budget exhausted")
+            i = ((splitmix64(h ^ (tag | t)) >> 32) * n) >> 32
+            t += 1
+            if i not in chosen:
+                chosen.append(i)
+        out.append(np.array([cells[i] for i in chosen], np.int32).reshape(-1, 2))
+    return out[0], out[1]

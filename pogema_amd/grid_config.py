@@ -16,8 +16,11 @@ MOVES = [[0, 0], [-1, 0], [1, 0], [0, -1], [0, 1]]  # noop, up, down, left, righ
 
 def str_map_to_list(str_map: str, free: str = ".", obstacle: str = "#"):
     """Parse a text map: '.' free, '#' obstacle; a lowercase letter marks an agent start and the same
-    letter in uppercase its target (both on free cells).  Returns (rows, agents_xy, targets_xy)."""
+    letter in uppercase its target (both on free cells); '@' a possible start cell, '$' a possible target cell,
+    '!' both (recalled from upstream, conf. medium).  Returns (rows, agents_xy, targets_xy) and leaves the possible
+    cells in `str_map_to_list.possible` = (possible_agents_xy, possible_targets_xy)."""
     rows, agents, targets = [], {}, {}
+    possible_agents, possible_targets = [], []
     for i, line in enumerate(str_map.split()):
         row = []
         for j, ch in enumerate(line):
@@ -27,6 +30,12 @@ def str_map_to_list(str_map: str, free: str = ".", obstacle: str = "#"):
                 row.append(OBSTACLE)
             elif ch.isalpha():
                 (targets if ch.isupper() else agents)[ch.lower()] = (i, j)
+                row.append(FREE)
+            elif ch in "@$!":
+                if ch in "@!":
+                    possible_agents.append([i, j])
+                if ch in "$!":
+                    possible_targets.append([i, j])
                 row.append(FREE)
             else:
                 raise KeyError(f"unsupported symbol {ch!r} at line {i}")
@@ -42,6 +51,7 @@ def str_map_to_list(str_map: str, free: str = ".", obstacle: str = "#"):
         targets_xy.append(list(targets[name]))
     if set(targets) - set(agents):
         raise KeyError("target without an agent on the map")
+    str_map_to_list.possible = (possible_agents, possible_targets)
     return rows, agents_xy, targets_xy
 
 
@@ -108,6 +118,11 @@ class GridConfig(BaseModel):
             if isinstance(self.map, str):
                 rows, agents_xy, targets_xy = str_map_to_list(self.map)
                 object.__setattr__(self, "map", rows)
+                pa, pt = str_map_to_list.possible
+                if pa and self.possible_agents_xy is None:
+                    object.__setattr__(self, "possible_agents_xy", pa)
+                if pt and self.possible_targets_xy is None:
+                    object.__setattr__(self, "possible_targets_xy", pt)
                 if agents_xy and self.agents_xy is None and self.targets_xy is None:
                     object.__setattr__(self, "agents_xy", agents_xy)
                     object.__setattr__(self, "targets_xy", targets_xy)

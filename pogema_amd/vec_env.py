@@ -42,8 +42,9 @@ class VecPogema:
         self.grid_config = grid_config if grid_config is not None else GridConfig(num_agents=2)
         gc = self.grid_config
         self.observation_type = gc.observation_type  # 'default' tensor, or 'POMAPF' / 'MAPF' dict views
-        if gc.possible_agents_xy is not None or gc.possible_targets_xy is not None:
-            raise NotImplementedError("possible_agents_xy / possible_targets_xy are not supported by the engine's generator")
+        self._possible = gc.possible_agents_xy is not None or gc.possible_targets_xy is not None
+        if self._possible and (gc.possible_agents_xy is None or gc.possible_targets_xy is None or gc.map is None):
+            raise ValueError("possible_agents_xy and possible_targets_xy must be given together, with an explicit `map`")
         if gc.persistent:
             raise NotImplementedError("persistent=True (PersistentWrapper / step_back) is outside the hot-path scope")
         if not torch.cuda.is_available():
@@ -64,7 +65,8 @@ class VecPogema:
         # wrapper with a fixed seed).  auto_reset="regenerate": it gets a NEW random instance instead (the wrapper with
         # seed=None), drawn on the device right after the step kernel, no host round trip (pgx_regenerate).
         self.regenerate = auto_reset == "regenerate"
-        if self.regenerate and (gc.observation_type != "default" or (gc.map is not None and gc.agents_xy is not None)):
+        if self.regenerate and (gc.observation_type != "default" or (gc.map is not None and gc.agents_xy is not None)
+                                or gc.possible_agents_xy is not None):
             raise NotImplementedError("auto_reset='regenerate' needs random instances and observation_type='default'")
         self.auto_reset = bool(auto_reset)
         self.reuse_buffers = bool(reuse_buffers)
@@ -134,6 +136,9 @@ class VecPogema:
             if gc.agents_xy is not None:
                 agents[:] = np.asarray(gc.agents_xy, dtype=np.int32)[None]
                 targets[:] = np.asarray(gc.targets_xy, dtype=np.int32)[None]
+            elif self._possible:
+                from .generator_host import place_from_possible
+                agents, targets = place_from_possible(B, seed0, gc.possible_agents_xy, gc.possible_targets_xy, A)
             else:
                 _lib.check(self._lib.pgx_place_agents(B, H, Wd, A, seed0, 10, 0, one.ctypes.data, 1,
                                                       agents.ctypes.data, targets.ctypes.data))
@@ -222,9 +227,9 @@ class VecPogema:
         seed + env_index_base + i; `generate()` yields the same instances on the host) and returns (obs, infos).
         With an explicit `map` AND `agents_xy`/`targets_xy` in the GridConfig nothing is random: that state is installed."""
         gc = self.grid_config
-        if gc.map is not None and gc.agents_xy is not None:
+        if gc.map is not None and (gc.agents_xy is not None or self._possible):
             obstacles, agents, targets = self.generate(seed)
-            obs = self.reset_from_state(obstacles, agents, targets, validate=False)
+            obs = self.reset_from_state(obstacles, agents, targets, validate=self._possible)
         else:
             if gc.agents_xy is not None:
                 raise NotImplementedError("agents_xy/targets_xy need an explicit `map`")
@@ -249,8 +254,9 @@ class VecPogema:
         if mask.numel() != self.batch:
             raise ValueError(f"mask must have {self.batch} entries")
         gc = self.grid_config
-        if gc.map is not None and gc.agents_xy is not None:
-            raise NotImplementedError("reset_where draws random instances; this GridConfig fixes map and agents")
+        if gc.map is not None and (gc.agents_xy is not None or self._possible):
+            raise NotImplementedError("reset_where draws random instances on the device; this GridConfig fixes the "
+                                      "agents or restricts them to possible_*_xy (host path)")
         if seed is None:
             seed = self._reset_seed
         shared = self._shared_map_tensor()

@@ -194,3 +194,17 @@ def test_integration_views():
     sf.close()
     with pytest.raises(NotImplementedError):
         pogema_v0(GridConfig(num_agents=2, integration="PyMARL"))
+
+
+def test_possible_positions_reset():
+    """GridConfig.possible_agents_xy / possible_targets_xy: starts and targets come from the given cells only."""
+    from oracle import generator_oracle as G
+    from pogema_amd import GridConfig, VecPogema
+    gc = GridConfig(map="@.#$\n!..#\n.$@.\n..!.", num_agents=3, obs_radius=2, seed=8)
+    env = VecPogema(gc, batch=5, env_index_base=2)
+    env.reset(seed=8)
+    st = env.get_state()
+    for b in range(5):
+        ra, rt = G.place_from_possible(0, 8 + 2 + b, gc.possible_agents_xy, gc.possible_targets_xy, 3)
+        assert np.array_equal(st["agents_xy"][b].cpu().numpy(), ra) and np.array_equal(st["targets_xy"][b].cpu().numpy(), rt)
+    env.close()

@@ -129,3 +129,20 @@ def test_generator_labels_are_min_indices():
         idx = [x * 15 + y for x, y in comp]
         assert all(lab[x, y] == min(idx) for x, y in comp)
     assert (lab[obst == 1] == -1).all()
+
+
+def test_possible_positions_host_equals_oracle():
+    """`possible_agents_xy` / `possible_targets_xy` (host numpy path of the product) == its oracle restatement."""
+    from oracle import generator_oracle as G
+    from pogema_amd.generator_host import place_from_possible
+    pa = [(0, 0), (0, 3), (2, 2), (4, 1), (5, 5), (1, 4)]
+    pt = [(3, 3), (0, 1), (5, 0), (2, 4)]
+    agents, targets = place_from_possible(6, 100, pa, pt, 3)
+    for b in range(6):
+        ra, rt = G.place_from_possible(0, 100 + b, pa, pt, 3)
+        assert np.array_equal(agents[b], ra) and np.array_equal(targets[b], rt)
+        assert len({tuple(p) for p in agents[b]}) == 3 and len({tuple(p) for p in targets[b]}) == 3
+        assert all(tuple(p) in pa for p in agents[b].tolist()) and all(tuple(p) in pt for p in targets[b].tolist())
+    full, _ = place_from_possible(1, 5, pa, pt, 4)  # all four targets are used when A == len(list)
+    with pytest.raises(OverflowError):
+        place_from_possible(1, 0, pa, pt, 5)

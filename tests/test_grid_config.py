@@ -56,3 +56,11 @@ def test_explicit_positions_set_num_agents():
 def test_str_map_to_list_roundtrip():
     rows, a, t = str_map_to_list("#.\n.#")
     assert rows == [[1, 0], [0, 1]] and a == [] and t == []
+
+
+def test_string_map_possible_positions():
+    from pogema_amd import GridConfig
+    gc = GridConfig(map="@.#$\n!..#\n.$@.", num_agents=2)
+    assert gc.map == [[0, 0, 1, 0], [0, 0, 0, 1], [0, 0, 0, 0]]
+    assert gc.possible_agents_xy == [[0, 0], [1, 0], [2, 2]] and gc.possible_targets_xy == [[0, 3], [1, 0], [2, 1]]
+    assert gc.agents_xy is None and gc.num_agents == 2

@@ -187,6 +187,17 @@ int pgx_observe(pgx_env* env, void* obs, void* stream);
 int pgx_get_state(pgx_env* env, int32_t* agent_xy, int32_t* target_xy, uint8_t* is_active,
                   int32_t* elapsed, uint8_t* occupancy, void* stream);
 
+/* ---- snapshot / restore -------------------------------------------------------------------------- */
+/* The complete engine state (maps, bitmaps, agent/target cells, initial state, active flags, step counters, metric
+ * accumulators, generation counters, lifelong tables and draw counters) as one opaque device blob of
+ * pgx_snapshot_bytes() bytes.  Replaces `PersistentWrapper`'s per-step state history / `step_back` (upstream
+ * pogema/wrappers/persistence.py) and gives checkpoint-resume: a loaded snapshot continues bit-identically.
+ * The blob is only valid for a handle of the same configuration (checked: ABI version, batch, agents).
+ * Both calls synchronise `stream` once for the 16-byte header; the payload copies are asynchronous. */
+int64_t pgx_snapshot_bytes(pgx_env* env);
+int pgx_save_snapshot(pgx_env* env, void* blob, void* stream);
+int pgx_load_snapshot(pgx_env* env, const void* blob, void* stream);
+
 /* ---- host-side synthetic map generator ------------------------------------------------------------ */
 /* Fills host buffers with `batch` random solvable instances: Bernoulli(density) obstacles, starts and
  * targets on distinct free cells with each start/target pair in one 4-connected component.

@@ -45,6 +45,7 @@ METRIC_NAMES = ("ISR", "CSR", "ep_length", "SoC", "makespan", "avg_throughput")
 EXPORTED_SYMBOLS = (
     "pgx_abi_version", "pgx_last_error", "pgx_create", "pgx_destroy", "pgx_obs_elems", "pgx_agent_elems",
     "pgx_reset_from_state", "pgx_reset_random", "pgx_regenerate", "pgx_regenerate_failures", "pgx_get_map", "pgx_step", "pgx_observe", "pgx_set_metrics_buffers", "pgx_get_state", "pgx_generate", "pgx_place_agents",
+    "pgx_snapshot_bytes", "pgx_save_snapshot", "pgx_load_snapshot",
 )
 
 
@@ -99,6 +100,11 @@ def load() -> C.CDLL:
     lib.pgx_regenerate_failures.argtypes = [vp, vp]
     lib.pgx_regenerate_failures.restype = i64
     lib.pgx_get_map.argtypes = [vp, vp, vp]
+    lib.pgx_snapshot_bytes.argtypes = [vp]
+    lib.pgx_snapshot_bytes.restype = i64
+    lib.pgx_save_snapshot.argtypes = [vp, vp, vp]
+    lib.pgx_load_snapshot.argtypes = [vp, vp, vp]
+    lib.pgx_save_snapshot.restype = lib.pgx_load_snapshot.restype = C.c_int
     lib.pgx_step.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     lib.pgx_observe.argtypes = [vp, vp, vp]
     lib.pgx_set_metrics_buffers.argtypes = [vp, vp, vp]

@@ -392,6 +392,78 @@ int64_t pgx_regenerate_failures(pgx_env* e, void* stream) {
     return (int64_t)n;
 }
 
+// ---- snapshot / restore of the complete engine state (checkpoint-resume, `step_back`) ---------------------
+extern "C++" {
+namespace {
+struct Segment {
+    void* ptr;
+    size_t bytes;
+};
+std::vector<Segment> snapshot_segments(pgx_env* e) {
+    const pgx_config& c = e->cfg;
+    const size_t B = (size_t)c.batch, BA = B * c.num_agents, cells = (size_t)c.height * c.width;
+    std::vector<Segment> seg = {
+        {e->pos, BA * 4}, {e->tgt, BA * 4}, {e->pos0, BA * 4}, {e->tgt0, BA * 4}, {e->active, BA},
+        {e->elapsed, B * 4}, {e->macc, B * sizeof(int4)}, {e->epoch, B * 4}, {e->map_u8, B * cells},
+        {e->obst, B * e->bmw * 4},
+    };
+    if (c.on_target == PGX_ON_TARGET_RESTART) {
+        seg.push_back({e->tcount, BA * 4});
+        seg.push_back({e->comp_begin, B * cells * 4});
+        seg.push_back({e->comp_len, B * cells * 4});
+        seg.push_back({e->comp_cells, B * cells * 4});
+    }
+    return seg;
+}
+size_t aligned16(size_t n) { return (n + 15) & ~(size_t)15; }
+}  // namespace
+}  // extern "C++"
+
+int64_t pgx_snapshot_bytes(pgx_env* e) {
+    if (!e) return 0;
+    size_t total = 16;  // header: magic, abi version, batch, agents
+    for (const Segment& s : snapshot_segments(e)) total += aligned16(s.bytes);
+    return (int64_t)total;
+}
+
+int pgx_save_snapshot(pgx_env* e, void* blob, void* stream) {
+    if (!e || !blob) return fail(PGX_E_INVALID, "pgx_save_snapshot: null argument");
+    if (!e->has_state) return fail(PGX_E_STATE, "pgx_save_snapshot called before a reset");
+    DeviceGuard guard(e->device);
+    if (guard.err != hipSuccess) return fail(PGX_E_HIP, "cannot select device: %s", hipGetErrorString(guard.err));
+    hipStream_t s = (hipStream_t)stream;
+    const int32_t header[4] = {0x50475853 /* 'PGXS' */, PGX_ABI_VERSION, e->cfg.batch, e->cfg.num_agents};
+    PGX_HIP(hipMemcpyAsync(blob, header, sizeof header, hipMemcpyHostToDevice, s));
+    PGX_HIP(hipStreamSynchronize(s));  // `header` lives on this stack frame
+    size_t off = 16;
+    for (const Segment& g : snapshot_segments(e)) {
+        PGX_HIP(hipMemcpyAsync((char*)blob + off, g.ptr, g.bytes, hipMemcpyDeviceToDevice, s));
+        off += aligned16(g.bytes);
+    }
+    return PGX_OK;
+}
+
+int pgx_load_snapshot(pgx_env* e, const void* blob, void* stream) {
+    if (!e || !blob) return fail(PGX_E_INVALID, "pgx_load_snapshot: null argument");
+    DeviceGuard guard(e->device);
+    if (guard.err != hipSuccess) return fail(PGX_E_HIP, "cannot select device: %s", hipGetErrorString(guard.err));
+    hipStream_t s = (hipStream_t)stream;
+    int32_t header[4] = {0, 0, 0, 0};
+    PGX_HIP(hipMemcpyAsync(header, blob, sizeof header, hipMemcpyDeviceToHost, s));
+    PGX_HIP(hipStreamSynchronize(s));
+    if (header[0] != 0x50475853 || header[1] != PGX_ABI_VERSION || header[2] != e->cfg.batch ||
+        header[3] != e->cfg.num_agents)
+        return fail(PGX_E_INVALID, "snapshot does not belong to this configuration (magic %08x, abi %d, batch %d, agents %d)",
+                    (unsigned)header[0], header[1], header[2], header[3]);
+    size_t off = 16;
+    for (const Segment& g : snapshot_segments(e)) {
+        PGX_HIP(hipMemcpyAsync(g.ptr, (const char*)blob + off, g.bytes, hipMemcpyDeviceToDevice, s));
+        off += aligned16(g.bytes);
+    }
+    e->has_state = true;
+    return PGX_OK;
+}
+
 int pgx_get_map(pgx_env* e, uint8_t* obstacles, void* stream) {
     if (!e || !obstacles) return fail(PGX_E_INVALID, "pgx_get_map: null argument");
     if (!e->has_state) return fail(PGX_E_STATE, "pgx_get_map called before a reset");

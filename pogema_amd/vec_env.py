@@ -346,6 +346,22 @@ class VecPogema:
         return out
 
     # ------------------------------------------------------------------------------------------
+    def save_state(self) -> torch.Tensor:
+        """Opaque device snapshot of the complete engine state (checkpoint / `step_back`): `load_state(blob)` on a
+        VecPogema of the same configuration continues bit-identically.  `blob.cpu()` can be written to disk."""
+        blob = torch.empty(int(self._lib.pgx_snapshot_bytes(self._handle)), dtype=torch.uint8, device=self.device)
+        _lib.check(self._lib.pgx_save_snapshot(self._handle, blob.data_ptr(), self._stream()))
+        extra = None if self._initial is None else tuple(t.clone() for t in self._initial)
+        return {"engine": blob, "initial": extra, "reset_seed": self._reset_seed}
+
+    def load_state(self, state) -> None:
+        blob = state["engine"].to(self.device).contiguous()
+        if blob.numel() != int(self._lib.pgx_snapshot_bytes(self._handle)):
+            raise ValueError("snapshot size does not match this environment's configuration")
+        _lib.check(self._lib.pgx_load_snapshot(self._handle, blob.data_ptr(), self._stream()))
+        self._initial = None if state["initial"] is None else tuple(t.to(self.device).clone() for t in state["initial"])
+        self._reset_seed = state["reset_seed"]
+
     def get_state(self, occupancy: bool = False):
         B, A, r = self.batch, self.num_agents, self.obs_radius
         dev = self.device

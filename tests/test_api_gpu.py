@@ -208,3 +208,36 @@ def test_possible_positions_reset():
         ra, rt = G.place_from_possible(0, 8 + 2 + b, gc.possible_agents_xy, gc.possible_targets_xy, 3)
         assert np.array_equal(st["agents_xy"][b].cpu().numpy(), ra) and np.array_equal(st["targets_xy"][b].cpu().numpy(), rt)
     env.close()
+
+
+@pytest.mark.parametrize("on_target,auto_reset", [("finish", True), ("restart", False), ("finish", "regenerate")])
+def test_snapshot_restore_continues_bit_identically(on_target, auto_reset):
+    """save_state / load_state (pgx_save_snapshot / pgx_load_snapshot): checkpoint-resume and `step_back`."""
+    import torch
+    from pogema_amd import GridConfig, VecPogema
+    B, S, A = 10, 12, 6
+    gc = GridConfig(size=S, num_agents=A, obs_radius=3, density=0.2, seed=17, on_target=on_target, max_episode_steps=5,
+                    collision_system="soft")
+    env = VecPogema(gc, batch=B, auto_reset=auto_reset)
+    env.reset(seed=17)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    acts = [torch.randint(0, 5, (B, A), generator=gen, device="cuda") for _ in range(14)]
+    for a in acts[:4]:
+        env.step(a)
+    snap = env.save_state()
+    first = [tuple(t.clone() for t in env.step(a)[:4]) for a in acts[4:]]
+    end_state = {k: v.clone() for k, v in env.get_state().items()}
+    # (1) step back in the same handle
+    env.load_state(snap)
+    again = [tuple(t.clone() for t in env.step(a)[:4]) for a in acts[4:]]
+    # (2) resume in a fresh handle (a checkpoint that went through host memory)
+    other = VecPogema(gc, batch=B, auto_reset=auto_reset)
+    other.load_state({"engine": snap["engine"].cpu(), "initial": snap["initial"], "reset_seed": snap["reset_seed"]})
+    resumed = [tuple(t.clone() for t in other.step(a)[:4]) for a in acts[4:]]
+    for ref, b, c in zip(first, again, resumed):
+        for x, y, z in zip(ref, b, c):
+            assert torch.equal(x, y) and torch.equal(x, z)
+    for k, v in other.get_state().items():
+        assert torch.equal(v, end_state[k])
+    env.close()
+    other.close()

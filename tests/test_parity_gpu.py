@@ -107,3 +107,71 @@ def test_random_outside(geom):
     ref = oracle_rollout(obstacles, agents, targets, actions, **kw)
     got = engine_rollout(obstacles, agents, targets, actions, **kw)
     assert_rollouts_equal(ref, got, f"random outside/{name}")
+
+
+def _corridor_case(A, order, blocked_front):
+    """A one-row corridor with A agents standing shoulder to shoulder, all pushing right: the longest possible
+    'the agent in front of me must move first' chain.  `order` permutes which agent index stands where."""
+    Wd = A + 2
+    obstacles = np.zeros((1, 3, Wd), np.uint8)
+    obstacles[0, 0, :] = 1
+    obstacles[0, 2, :] = 1
+    if blocked_front:
+        obstacles[0, 1, A] = 1  # wall right in front of the head of the line
+    cols = np.arange(A)
+    agents = np.zeros((1, A, 2), np.int32)
+    agents[0, :, 0] = 1
+    agents[0, order, 1] = cols  # agent order[k] stands in column k
+    targets = agents.copy()
+    targets[0, :, 1] = (agents[0, :, 1] + 1) % Wd  # anywhere free; irrelevant for 'nothing'
+    targets[0, :, 1] = np.where(obstacles[0, 1, targets[0, :, 1]] != 0, 0, targets[0, :, 1])
+    return obstacles, agents, targets
+
+
+@pytest.mark.parametrize("A", [8, 64, 200, 256])
+@pytest.mark.parametrize("blocked_front", [False, True])
+def test_longest_follow_chains(A, blocked_front):
+    """Pointer-doubling closure at its worst case (ceil(log2 A) rounds, across waves for A > 64): a whole line moves
+    or stays together depending on the head, for ascending, descending and shuffled index orders."""
+    rng = np.random.default_rng(A)
+    orders = [np.arange(A), np.arange(A)[::-1].copy(), rng.permutation(A)]
+    right = np.full((1, 1, A), 4, np.int64)
+    acts = np.concatenate([right, right, random_actions(4, 1, A, 5), right])
+    for order in orders:
+        obstacles, agents, targets = _corridor_case(A, order, blocked_front)
+        for collision in COLLISIONS:
+            kw = dict(obs_radius=2, collision_system=collision, on_target="nothing", max_episode_steps=64, auto_reset=False)
+            ref = oracle_rollout(obstacles, agents, targets, acts, **kw)
+            got = engine_rollout(obstacles, agents, targets, acts, **kw)
+            assert_rollouts_equal(ref, got, f"chain A={A} blocked={blocked_front} {collision}")
+
+
+@pytest.mark.parametrize("A", [12, 64, 128])
+def test_rotation_cycles(A):
+    """Agents on a closed loop all stepping forward (cyclic rotation): allowed under 'soft', impossible under
+    'priority' / 'block_both' -- a chain with no head, the closure's other extreme."""
+    n = A // 4 + 1  # square ring with side n holds 4(n-1) = A cells
+    ring = [(0, j) for j in range(n - 1)] + [(i, n - 1) for i in range(n - 1)] + \
+           [(n - 1, j) for j in range(n - 1, 0, -1)] + [(i, 0) for i in range(n - 1, 0, -1)]
+    assert len(ring) == A
+    obstacles = np.ones((1, n, n), np.uint8)
+    for c in ring:
+        obstacles[0][c] = 0
+    step_to = {(0, 1): 4, (1, 0): 2, (0, -1): 3, (-1, 0): 1}
+    rng = np.random.default_rng(1)
+    for order in (np.arange(A), rng.permutation(A)):
+        agents = np.zeros((1, A, 2), np.int32)
+        acts = np.zeros((1, 1, A), np.int64)
+        for k in range(A):
+            cur, nxt = ring[k], ring[(k + 1) % A]
+            agents[0, order[k]] = cur
+            acts[0, 0, order[k]] = step_to[(nxt[0] - cur[0], nxt[1] - cur[1])]
+        targets = agents.copy()
+        rollout_acts = np.concatenate([acts, random_actions(3, 1, A, 2)])
+        for collision in COLLISIONS:
+            kw = dict(obs_radius=2, collision_system=collision, on_target="nothing", max_episode_steps=64, auto_reset=False)
+            ref = oracle_rollout(obstacles, agents, targets, rollout_acts, **kw)
+            got = engine_rollout(obstacles, agents, targets, rollout_acts, **kw)
+            assert_rollouts_equal(ref, got, f"rotation A={A} {collision}")
+            moved = (ref["agents_xy"][0, 0] != agents[0]).any(axis=1)
+            assert moved.all() if collision == "soft" else not moved.any()

@@ -123,3 +123,42 @@ def test_determinism_and_reset_restores_initial_state():
         outs.append(torch.stack(trace))
         env.close()
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("collision", ["priority", "block_both", "soft"])
+@pytest.mark.parametrize("on_target", ["finish", "restart"])
+def test_soak_parity_with_c_oracle(collision, on_target):
+    """Long rollout (150 steps, 1024 envs x 64 agents on 64x64, several episodes per env): state, flags, rewards and
+    metrics every step, full observations every 25th -- rare events (long chains, multi-way conflicts, late
+    arrivals, lifelong re-targets) against the literal C port."""
+    from oracle.c_oracle import COracle
+    B, size, A, r, T, max_steps = 1024, 64, 64, 5, 150, 32
+    obstacles, agents, targets = generate_instances(B, size, size, A, 0.3, 99)
+    rng = np.random.default_rng(8)
+    ref = COracle(B, size, size, A, r, collision, on_target, max_steps, True, seed=5, env_index_base=40)
+    ref.reset(obstacles, agents, targets)
+    from pogema_amd import GridConfig, VecPogema
+    gc = GridConfig(size=size, num_agents=A, obs_radius=r, collision_system=collision, on_target=on_target,
+                    max_episode_steps=max_steps, seed=5, density=0.3)
+    env = VecPogema(gc, batch=B, auto_reset=True, env_index_base=40)
+    env.reset_from_state(obstacles, agents, targets, validate=False)
+    threads = min(32, len(__import__("os").sched_getaffinity(0)))
+    for t in range(T):
+        # biased walk towards the targets half of the time, so that agents actually arrive and conflict at goals
+        acts = rng.integers(0, 5, size=(B, A)).astype(np.int64)
+        check_obs = t % 25 == 24
+        robs, rrew, rterm, rtrunc, ract = ref.step(acts, nthreads=threads, compute_obs=check_obs)
+        obs, rew, term, trunc, info = env.step(torch.from_numpy(acts).cuda(), compute_obs=check_obs)
+        st, rst = env.get_state(), ref.get_state()
+        assert np.array_equal(st["agents_xy"].cpu().numpy(), rst["agents_xy"]), f"step {t}: positions"
+        assert np.array_equal(st["targets_xy"].cpu().numpy(), rst["targets_xy"]), f"step {t}: targets"
+        assert np.array_equal(st["is_active"].cpu().numpy(), rst["is_active"]) and np.array_equal(st["elapsed"].cpu().numpy(), rst["elapsed"])
+        assert np.array_equal(term.cpu().numpy(), rterm) and np.array_equal(trunc.cpu().numpy(), rtrunc)
+        np.testing.assert_allclose(rew.cpu().numpy(), rrew, rtol=0, atol=1e-6)
+        done = info["episode_done"].cpu().numpy().astype(bool)
+        assert np.array_equal(done, ref.episode_done.astype(bool))
+        np.testing.assert_allclose(info["metrics"].cpu().numpy()[done], ref.metrics[done], rtol=1e-6, atol=1e-6)
+        if check_obs:
+            assert np.array_equal(obs.cpu().numpy(), robs), f"step {t}: observations"
+    env.close()
+    ref.close()

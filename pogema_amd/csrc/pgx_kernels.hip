@@ -66,13 +66,13 @@ __device__ __forceinline__ uint32_t move_c22(uint32_t c, int a) {
 template <int G>
 __device__ __forceinline__ uint32_t rot1(uint32_t v, int src_lane) {
     if constexpr (G == 64) {
-        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x134 /* wave_rol:1 */, 0xF, 0xF, false);
+        return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x134 /* wave_rol:1 */, 0xF, 0xF, true);
     } else if constexpr (G == 16) {
-        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x12F /* row_ror:15 */, 0xF, 0xF, false);
+        return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x12F /* row_ror:15 */, 0xF, 0xF, true);
     } else if constexpr (G == 4) {
-        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x39 /* quad_perm:[1,2,3,0] */, 0xF, 0xF, false);
+        return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x39 /* quad_perm:[1,2,3,0] */, 0xF, 0xF, true);
     } else if constexpr (G == 2) {
-        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, false);
+        return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, true);
     } else {
         return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v);
     }
@@ -90,29 +90,34 @@ __device__ __forceinline__ bool group_any(bool pred, int gbase) {
     }
 }
 
-// All-pairs sweep, branch-free and VALU-only.  For the lane's own agent i it min-reduces over the
-// OTHER agents j of the environment:
-//   okey = ((vis_j ^ want_i) << 10) | j                -> okey < 1024 <=> some agent stands on want_i,
-//                                                         and okey is then that agent's index
-//   ckey = ((want_j ^ want_i) << 10) | ((i-1-j)&1023)  -> ckey < 1024 <=> some other agent claims want_i;
-//                                                         ckey < i     <=> a LOWER-index one does, and
-//                                                         i-1-ckey is the largest such index
-__device__ __forceinline__ void pair_min(uint32_t cr, uint32_t dr, uint32_t want, int i, int j, uint32_t& okey,
-                                         uint32_t& ckey) {
-    okey = min(okey, ((cr ^ want) << 10) | (uint32_t)j);
-    ckey = min(ckey, ((dr ^ want) << 10) | (uint32_t)((i - 1 - j) & 1023));
+// All-pairs sweep, branch-free and VALU-only.  Every agent j publishes two words that carry its index in the low
+// 10 bits, P_j = (vis_j << 10) | j and Q_j = (want_j << 10) | j; the lane of agent i holds WSH = want_i << 10.
+// For every OTHER agent j of the environment (values arrive by DPP rotation):
+//   x = P_j ^ WSH  -> x < 1024 <=> j stands on want_i, and then x == j               okey = min x
+//   y = Q_j ^ WSH  -> y < 1024 <=> j claims want_i too, and then y == j               cany = min y
+//   z = (i-1) - y  -> z < i    <=> that claimant has a LOWER index; the smallest z is the largest such index
+//                     (unsigned wrap-around keeps every other y at z >= i)              zmin = min z
+// 2 DPP moves + 2 xor + 1 sub + 3 min per partner (the first version recomputed j and the distance per step: 14).
+struct SweepAcc {
+    uint32_t okey, cany, zmin;
+};
+__device__ __forceinline__ void pair_min(uint32_t pj, uint32_t qj, uint32_t wsh, uint32_t im1, SweepAcc& a) {
+    const uint32_t y = qj ^ wsh;
+    a.okey = min(a.okey, pj ^ wsh);
+    a.cany = min(a.cany, y);
+    a.zmin = min(a.zmin, im1 - y);
 }
 
-// One slot of G partners whose (vis, want) values sit in the lanes of this wave's group: G-1 DPP
-// rotations (plus the unrotated value when the slot belongs to another wave, `with_k0`).
+// One slot of G partners whose (P, Q) words sit in the lanes of this wave's group: G-1 DPP rotations (plus the
+// unrotated words when the slot belongs to another wave, `with_k0`).
 template <int G>
-__device__ __forceinline__ void sweep_slot(uint32_t cr, uint32_t dr, bool with_k0, int jbase, int alane, int src,
-                                           uint32_t want, int i, uint32_t& okey, uint32_t& ckey) {
-    if (with_k0) pair_min(cr, dr, want, i, jbase + alane, okey, ckey);
+__device__ __forceinline__ void sweep_slot(uint32_t pj, uint32_t qj, bool with_k0, int src, uint32_t wsh, uint32_t im1,
+                                           SweepAcc& a) {
+    if (with_k0) pair_min(pj, qj, wsh, im1, a);
     for (int k = 1; k < G; ++k) {
-        cr = rot1<G>(cr, src);
-        dr = rot1<G>(dr, src);
-        pair_min(cr, dr, want, i, jbase + ((alane + k) & (G - 1)), okey, ckey);
+        pj = rot1<G>(pj, src);
+        qj = rot1<G>(qj, src);
+        pair_min(pj, qj, wsh, im1, a);
     }
 }
 
@@ -294,30 +299,33 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
             const bool claims = (p.collision == COLLISION_BLOCK_BOTH) ? active : mover;
             const uint32_t want = claims ? d : NOCELL_B;
             const int i = agent;
-            uint32_t okey = KEY_NONE, ckey = KEY_NONE;
+            SweepAcc acc = {KEY_NONE, KEY_NONE, KEY_NONE};
+            const uint32_t wsh = want << 10, im1 = (uint32_t)(i - 1);
+            const uint32_t pw = (vis << 10) | (uint32_t)i, qw = wsh | (uint32_t)i;
             const int src = gbase + ((alane + 1) & (G - 1));
             if constexpr (MW) {
-                s_vis[tid] = vis;
-                s_want[tid] = want;
+                s_vis[tid] = pw;
+                s_want[tid] = qw;
                 lds_sync<true>();
                 for (int sj = 0; sj < nw; ++sj) {  // wave-uniform
                     const bool own = (sj == wave);
-                    const uint32_t cr = own ? vis : s_vis[sj * 64 + lane];
-                    const uint32_t dr = own ? want : s_want[sj * 64 + lane];
-                    sweep_slot<64>(cr, dr, !own, sj * 64, lane, src, want, i, okey, ckey);
+                    const uint32_t pj = own ? pw : s_vis[sj * 64 + lane];
+                    const uint32_t qj = own ? qw : s_want[sj * 64 + lane];
+                    sweep_slot<64>(pj, qj, !own, src, wsh, im1, acc);
                 }
             } else {
-                sweep_slot<G>(vis, want, false, 0, alane, src, want, i, okey, ckey);
+                sweep_slot<G>(pw, qw, false, src, wsh, im1, acc);
             }
+            const uint32_t okey = acc.okey;
 
             bool stay;
             if (p.collision == COLLISION_BLOCK_BOTH) {
                 // blocked <=> destination is someone's current cell or claimed twice.
-                stay = !mover || blocked || okey < 1024u || ckey < 1024u;
+                stay = !mover || blocked || okey < 1024u || acc.cany < 1024u;
             } else {
                 const int o = okey < 1024u ? (int)okey : -1;           // agent on my destination
-                const bool lower = ckey < (uint32_t)i;                 // a lower index claims it too
-                const int c1 = lower ? (i - 1 - (int)ckey) : -1;       // the largest such index
+                const bool lower = acc.zmin < (uint32_t)i;             // a lower index claims it too
+                const int c1 = lower ? (i - 1 - (int)acc.zmin) : -1;   // the largest such index
                 int nxt = mover ? o : -1;
                 if (p.collision == COLLISION_PRIORITY) {
                     // SURVEY A3 (agents move one by one in index order).  Agent i ends up moving iff
@@ -330,7 +338,7 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
                     stay = !mover || blocked || lower;
                     uint32_t want_of_o;
                     if constexpr (MW) {
-                        want_of_o = nxt >= 0 ? s_want[nxt] : NOCELL_B;
+                        want_of_o = nxt >= 0 ? (s_want[nxt] >> 10) : NOCELL_B;
                     } else {
                         const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute((gbase + (nxt < 0 ? alane : nxt)) << 2, (int)want);
                         want_of_o = nxt >= 0 ? got : NOCELL_B;

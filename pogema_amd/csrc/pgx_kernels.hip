@@ -4,17 +4,18 @@
 //   Pogema.step / move_agents / Grid.move / _obs() / MultiTimeLimit.step           rows A2..A13
 //
 // Design (DESIGN.md has the full story):
-//   * one WAVE owns one environment (or 64/G environments when num_agents <= 32, G = next pow2 of
-//     num_agents); lane = agent.  For num_agents > 64 each lane carries K = ceil(A/64) agents in
-//     registers and three more waves of the workgroup only help with the observation write.
-//   * collision resolution is register-resident: the agent-index-ordered semantics of the
-//     reference are reproduced with v_readlane / ds_bpermute broadcasts + 64-lane ballots; no
-//     global atomics, no per-cell tables in HBM.
-//   * the padded obstacle bitmap (1 bit per cell) is staged HBM -> LDS once per step, the occupancy
-//     bitmap is rebuilt in LDS from the agents' cells with LDS atomics, every (agent, channel,
-//     window-row) is reduced to one 32-bit row mask in LDS, and the float32 observation tensor is
-//     then produced as a flat, fully coalesced stream of 16-byte stores (the only large HBM
-//     stream of the kernel: 12*(2r+1)^2 bytes per agent-step).
+//   * one lane = one agent.  num_agents <= 64: a workgroup is ONE wave holding up to 64/G environments (G = next
+//     power of two of num_agents); num_agents > 64: ceil(A/64) symmetric waves per environment, partners of other
+//     waves and the transitive closure go through LDS.
+//   * collision resolution is register-resident: an all-pairs DPP sweep (index-carrying words, 7 instructions per
+//     partner) yields "who stands on my destination" and "which lower index claims it too"; the three collision
+//     systems of the reference are closed forms of those plus a pointer-doubling closure.  No global atomics, no
+//     per-cell tables in HBM.
+//   * the padded obstacle bitmap (1 bit per cell) is staged HBM -> LDS once per step, the occupancy bitmap is
+//     rebuilt in LDS from the agents' cells with LDS atomics, every (agent, channel, window-row) is reduced to one
+//     row mask (16-bit, aliased over the dead state, when the window side is <= 16), and the observation tensor is
+//     then produced as a flat, fully coalesced stream of 16-byte stores (float32: 12*(2r+1)^2 bytes per
+//     agent-step, the only large HBM stream of the kernel; uint8 optional).
 //   * integer indexing only -- no MFMA on purpose; the bound is HBM write bandwidth.
 #include <hip/hip_runtime.h>
 #include <stdint.h>

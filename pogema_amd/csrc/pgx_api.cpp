@@ -135,6 +135,7 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
     if (const char* f = getenv("PGX_EPW")) epw_override = atoi(f);
     // PGX_FLAGS bit1: force the generic (32-bit row mask) observation path
     e->geo = pgx::step_geometry(cfg->batch, A, e->bmw, e->W, !(e->flags & 2u), epw_override);
+    if (const char* f = getenv("PGX_STAGGER")) e->geo.stagger = atoi(f);  // tuning/diagnostic override
     if (e->geo.lds_bytes > 160 * 1024) {
         const size_t need = e->geo.lds_bytes;
         delete e;
@@ -491,6 +492,7 @@ static void fill_params(const pgx_env* e, pgx::StepParams& p) {
     p.auto_reset = c.auto_reset;
     p.flags = e->flags;
     p.epw = e->geo.epw;
+    p.stagger = e->geo.stagger;
     p.obs_u8 = e->cfg.obs_dtype == PGX_OBS_U8 ? 1 : 0;
     p.seed = c.seed;
     p.env_index_base = c.env_index_base;

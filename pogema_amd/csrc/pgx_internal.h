@@ -60,6 +60,7 @@ struct StepParams {
     int32_t mode, collision, on_target, max_steps, auto_reset, action_dtype;
     int32_t epw;       // environments per wave (single-wave blocks, num_agents <= 64)
     int32_t obs_u8;    // 1: `obs` is uint8 (one byte per cell) instead of float32
+    int32_t stagger;   // cohort stagger of the single-wave kernel (StepGeometry::stagger)
     uint32_t flags;    // tuning switches (PGX_FLAGS env var at pgx_create): bit0 = nontemporal obs stores
     uint64_t seed;
     int64_t env_index_base;
@@ -98,6 +99,7 @@ struct StepGeometry {
     int epw;          // environments per wave (1 when multi_wave)
     bool multi_wave;  // num_agents > 64: one environment per workgroup
     bool p16;         // window side <= 16: packed 16-bit row masks aliased over the LDS state
+    int stagger;      // > 0: odd wave slots sleep this many x 8128 cycles after issuing their loads
     size_t lds_bytes;
 };
 StepGeometry step_geometry(int batch, int A, int bmw, int W, bool allow_p16, int epw_override);

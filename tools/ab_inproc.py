@@ -10,7 +10,7 @@ import torch  # noqa: E402
 from pogema_amd import GridConfig, VecPogema  # noqa: E402
 
 WL = {"cfg1": (1024, 16, 8, 5), "cfg2": (8192, 64, 64, 5), "cfg3": (8192, 32, 16, 5), "cfg4": (4096, 256, 256, 7),
-      "a8big": (65536, 16, 8, 5), "a32": (8192, 32, 32, 5), "a32big": (32768, 32, 32, 5), "a24small": (512, 32, 24, 5), "half": (4096, 64, 64, 5), "three_q": (6144, 64, 64, 5)}
+      "a8big": (65536, 16, 8, 5), "a32": (8192, 32, 32, 5), "a32big": (32768, 32, 32, 5), "a24small": (512, 32, 24, 5), "half": (4096, 64, 64, 5), "three_q": (6144, 64, 64, 5), "quarter": (2048, 64, 64, 5), "eighth": (1024, 64, 64, 5)}
 wl = sys.argv[1]
 variants = sys.argv[2:]
 batch, size, agents, r = WL[wl]

@@ -177,6 +177,14 @@ int pgx_set_metrics_buffers(pgx_env* env, float* metrics, uint8_t* episode_done)
  * `reset()`. */
 int pgx_observe(pgx_env* env, void* obs, void* stream);
 
+/* Placement probe.  On MI355X the speed of the observation stream depends on WHERE the output buffer lives: equal
+ * 2 MiB-aligned hipMalloc'd buffers fall into tiers of ~140 / ~144 / ~153 us per configs[2] step on one and the same
+ * device (profiles/r1/placement_tiers.txt), presumably by how their physical pages spread over the HBM stacks.  This
+ * call writes the current observations into `obs` `reps` times and returns the average duration, so that a caller
+ * that owns a pool of candidate buffers can keep the well-placed ones (VecPogema(reuse_buffers=True) does).
+ * Synchronises `stream`.  Nothing in the engine's state changes. */
+int pgx_time_observe(pgx_env* env, void* obs, int32_t reps, float* microseconds, void* stream);
+
 /* ---- state export ------------------------------------------------------------------------------- */
 /* Replaces `Grid.get_agents_xy` / `get_targets_xy` / `is_active` / the occupancy array (`positions`).
  * Any pointer may be NULL.  All device pointers.

@@ -45,7 +45,7 @@ METRIC_NAMES = ("ISR", "CSR", "ep_length", "SoC", "makespan", "avg_throughput")
 EXPORTED_SYMBOLS = (
     "pgx_abi_version", "pgx_last_error", "pgx_create", "pgx_destroy", "pgx_obs_elems", "pgx_agent_elems",
     "pgx_reset_from_state", "pgx_reset_random", "pgx_regenerate", "pgx_regenerate_failures", "pgx_get_map", "pgx_step", "pgx_observe", "pgx_set_metrics_buffers", "pgx_get_state", "pgx_generate", "pgx_place_agents",
-    "pgx_snapshot_bytes", "pgx_save_snapshot", "pgx_load_snapshot",
+    "pgx_snapshot_bytes", "pgx_save_snapshot", "pgx_load_snapshot", "pgx_time_observe",
 )
 
 
@@ -100,6 +100,8 @@ def load() -> C.CDLL:
     lib.pgx_regenerate_failures.argtypes = [vp, vp]
     lib.pgx_regenerate_failures.restype = i64
     lib.pgx_get_map.argtypes = [vp, vp, vp]
+    lib.pgx_time_observe.argtypes = [vp, vp, i32, C.POINTER(C.c_float), vp]
+    lib.pgx_time_observe.restype = C.c_int
     lib.pgx_snapshot_bytes.argtypes = [vp]
     lib.pgx_snapshot_bytes.restype = i64
     lib.pgx_save_snapshot.argtypes = [vp, vp, vp]

@@ -554,6 +554,33 @@ int pgx_observe(pgx_env* e, void* obs, void* stream) {
     return PGX_OK;
 }
 
+int pgx_time_observe(pgx_env* e, void* obs, int32_t reps, float* microseconds, void* stream) {
+    if (!e || !obs || !microseconds) return fail(PGX_E_INVALID, "pgx_time_observe: null argument");
+    if (!e->has_state) return fail(PGX_E_STATE, "pgx_time_observe called before a reset");
+    if (reps < 1) reps = 3;
+    DeviceGuard guard(e->device);
+    if (guard.err != hipSuccess) return fail(PGX_E_HIP, "cannot select device: %s", hipGetErrorString(guard.err));
+    hipStream_t s = (hipStream_t)stream;
+    pgx::StepParams p;
+    fill_params(e, p);
+    p.mode = pgx::MODE_OBSERVE;
+    p.obs = static_cast<float*>(obs);
+    hipEvent_t a, b;
+    PGX_HIP(hipEventCreate(&a));
+    PGX_HIP(hipEventCreate(&b));
+    PGX_HIP(pgx::launch_step(p, e->geo, s));  // warm-up: first touch of the buffer
+    PGX_HIP(hipEventRecord(a, s));
+    for (int i = 0; i < reps; ++i) PGX_HIP(pgx::launch_step(p, e->geo, s));
+    PGX_HIP(hipEventRecord(b, s));
+    PGX_HIP(hipEventSynchronize(b));
+    float ms = 0.0f;
+    PGX_HIP(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    *microseconds = ms * 1000.0f / (float)reps;
+    return PGX_OK;
+}
+
 int pgx_get_state(pgx_env* e, int32_t* agent_xy, int32_t* target_xy, uint8_t* is_active, int32_t* elapsed,
                   uint8_t* occupancy, void* stream) {
     if (!e) return fail(PGX_E_INVALID, "pgx_get_state: null handle");

@@ -271,20 +271,48 @@ class VecPogema:
         return self._wrap_obs(self.observe())
 
     # ------------------------------------------------------------------------------------------
-    def _alloc_outputs(self):
+    def _alloc_outputs(self, with_obs: bool = True):
         B, A = self.batch, self.num_agents
         dev = self.device
-        return (torch.empty(self.obs_shape, dtype=self.obs_dtype, device=dev),
+        return (torch.empty(self.obs_shape, dtype=self.obs_dtype, device=dev) if with_obs else None,
                 torch.empty((B, A), dtype=torch.float32, device=dev),
                 torch.empty((B, A), dtype=torch.bool, device=dev),
                 torch.empty((B, A), dtype=torch.bool, device=dev),
                 torch.empty((B, A), dtype=torch.bool, device=dev))
 
+    # Placement of the double-buffered observation tensors (reuse_buffers=True).  Equal hipMalloc'd buffers fall into
+    # speed tiers on MI355X (~140 / ~144 / ~153 us per configs[2] step on one device, profiles/r1/placement_tiers.txt):
+    # where the physical pages live matters.  The engine's placement probe times a plain observation pass into a
+    # handful of candidates; the two fastest are kept, the rest go back to torch's allocator.
+    PLACEMENT_CANDIDATES = 8
+    PLACEMENT_MIN_BYTES = 64 << 20
+
+    def _pick_obs_buffers(self):
+        obs_bytes = int(np.prod(self.obs_shape)) * (4 if self.obs_dtype == torch.float32 else 1)
+        n = self.PLACEMENT_CANDIDATES if obs_bytes >= self.PLACEMENT_MIN_BYTES else 2
+        free, _ = torch.cuda.mem_get_info(self.device)
+        n = max(2, min(n, int(free * 0.5) // max(obs_bytes, 1)))
+        cands = [torch.empty(self.obs_shape, dtype=self.obs_dtype, device=self.device) for _ in range(n)]
+        if n == 2 or not self._has_state():
+            return cands[:2]
+        timed = []
+        us = C.c_float()
+        for t in cands:
+            _lib.check(self._lib.pgx_time_observe(self._handle, t.data_ptr(), 3, C.byref(us), self._stream()))
+            timed.append((float(us.value), t))
+        timed.sort(key=lambda x: x[0])
+        self.placement_us = [round(u, 2) for u, _ in timed]
+        return [timed[0][1], timed[1][1]]
+
+    def _has_state(self):
+        return self._initial is not None
+
     def _outputs(self):
         if not self.reuse_buffers:
             return self._alloc_outputs()
         if self._bufs is None:
-            self._bufs = [self._alloc_outputs(), self._alloc_outputs()]
+            obs_a, obs_b = self._pick_obs_buffers()
+            self._bufs = [(obs_a,) + self._alloc_outputs(False)[1:], (obs_b,) + self._alloc_outputs(False)[1:]]
         self._buf_i ^= 1
         return self._bufs[self._buf_i]
 

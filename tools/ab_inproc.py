@@ -25,6 +25,12 @@ for v in variants:
     env = VecPogema(GridConfig(size=size, num_agents=agents, obs_radius=r, density=0.3, seed=0, collision_system="soft"),
                     batch=batch, auto_reset=True, reuse_buffers=True)
     env.reset(seed=0)
+    # every variant writes into the SAME pair of observation buffers: buffer placement alone moves the kernel by up to
+    # 10 % (profiles/r1/placement_tiers.txt), which would otherwise drown the effect under test
+    if envs:
+        env._bufs = [(envs[0]._bufs[k][0],) + env._alloc_outputs(False)[1:] for k in range(2)]
+    else:
+        env._outputs()
     envs.append(env)
 acts = [torch.randint(0, 5, (batch, agents), device="cuda") for _ in range(8)]
 rounds, steps = 12, 60

@@ -203,10 +203,12 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
     const int wave = MW ? (tid >> 6) : 0;
     const int nw = NT >> 6;
     const int epw = MW ? 1 : p.epw;
-    // Workgroup -> environment slice.  Hardware places workgroup b on XCD b % 8; with PGX_FLAGS bit 3 the slices of
-    // one XCD are contiguous in memory (each XCD's L2 then writes back one contiguous eighth of the tensor).
+    // Workgroup -> environment slice.  Hardware places workgroup b on XCD b % 8; the slices of one XCD are made
+    // contiguous in memory, so each XCD's L2 writes back one contiguous eighth of the observation tensor: -11.5 % per
+    // configs[4] step (523 -> 465 us), -2 % on configs[2], neutral on short launches (buffer-controlled A/B,
+    // profiles/r1/controlled_ab.txt).  PGX_FLAGS bit 3 switches back to the identity mapping for A/B.
     int blk = blockIdx.x;
-    if (p.flags & 8u) {
+    if (!(p.flags & 8u)) {
         const int per_xcd = gridDim.x >> 3;
         if (blk < (per_xcd << 3)) blk = (blk & 7) * per_xcd + (blk >> 3);
     }
@@ -275,8 +277,8 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
             // odd hardware slots sleep for `stagger` x 8128 cycles.  The even slots run their state phase with half the
             // SIMD/LDS contention and start streaming early; the odd slots compute under that stream (their loads are
             // already in registers, their small state stores are never waited for) and follow.  Without this every
-            // wave runs the ~11 us state phase at the same time and HBM idles meanwhile.  Opt-in (PGX_STAGGER): the
-            // effect is box-dependent, -10 % ... +6.5 % per configs[2] step (profiles/r1/stagger_ab.txt).
+            // wave runs the ~11 us state phase at the same time and HBM idles meanwhile.  Enabled by step_geometry()
+            // for single-round launches of long streams (-2.3 % per configs[2] step, profiles/r1/controlled_ab.txt).
             uint32_t bmr[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) bmr[k] = (tid + 64 * k < n) ? g[tid + 64 * k] : 0u;
@@ -839,10 +841,16 @@ StepGeometry step_geometry(int batch, int A, int bmw, int W, bool allow_p16, int
         if (epw_override > 0) g.epw = epw_override < max_epw ? epw_override : max_epw;
     }
     g.p16 = allow_p16 && W <= 16;
-    // Cohort stagger (step_kernel phase 1) is OFF by default: measured between -10 % and +6.5 % per configs[2] step
-    // depending on the box (profiles/r1/stagger_ab.txt: it helps the boxes whose un-staggered kernel sits ~12 us above
-    // their pure store stream and hurts the ones that already match it).  PGX_STAGGER=<units> opts in.
-    g.stagger = 0;
+    // Cohort stagger (step_kernel phase 1): pays when every wave of the launch is resident at once (one round of at
+    // most 256 CUs x 32 waves, at least half of them used) and each wave streams for long (>= 32 KB of observations):
+    // -2.3 % per configs[2] step in a buffer-controlled A/B on two boxes (profiles/r1/controlled_ab.txt); with several
+    // rounds every odd-slot wave of every round would pay the delay.  PGX_STAGGER overrides (0 = off).
+    {
+        const long blocks = g.multi_wave ? batch : (batch + g.epw - 1) / g.epw;
+        const size_t stream_bytes = (size_t)g.epw * A * 3 * W * W * 4;
+        g.stagger = (!g.multi_wave && blocks <= 8192 && blocks >= 4096 && stream_bytes >= 32 * 1024 &&
+                     (size_t)g.epw * bmw <= 16 * 64) ? 6 : 0;
+    }
     const int NT = 64 * g.waves;
     const size_t agent_slots = g.multi_wave ? (size_t)NT : (size_t)g.epw * A;
     size_t state_words = (size_t)2 * g.epw * bmw + 2 * agent_slots;

@@ -9,6 +9,7 @@ only -- every computation happens in libpogema_amd.so (there is no eager/CPU fal
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import numpy as np
@@ -290,6 +291,8 @@ class VecPogema:
     def _pick_obs_buffers(self):
         obs_bytes = int(np.prod(self.obs_shape)) * (4 if self.obs_dtype == torch.float32 else 1)
         n = self.PLACEMENT_CANDIDATES if obs_bytes >= self.PLACEMENT_MIN_BYTES else 2
+        if os.environ.get("PGX_PLACEMENT") == "0":  # diagnostic: take the first two buffers as they come
+            n = 2
         free, _ = torch.cuda.mem_get_info(self.device)
         n = max(2, min(n, int(free * 0.5) // max(obs_bytes, 1)))
         cands = [torch.empty(self.obs_shape, dtype=self.obs_dtype, device=self.device) for _ in range(n)]

@@ -13,7 +13,9 @@ for wl in $WLS; do
   extra="--workload $wl"
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${wl}_stats -- python3 bench.py $extra > $OUT/${wl}_bench.json 2> $OUT/${wl}_stats.err
   for ctr in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/${wl}_$ctr -- python3 bench.py $extra --steps 20 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/${wl}_$ctr.err
+    # PGX_PLACEMENT=0: no placement-probe launches (they are MODE_OBSERVE launches of the same kernel and would dilute
+    # the per-step counter means)
+    PGX_PLACEMENT=0 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/${wl}_$ctr -- python3 bench.py $extra --steps 20 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/${wl}_$ctr.err
   done
 done
 for ctr in FETCH_SIZE WRITE_SIZE; do

@@ -134,7 +134,8 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
     int epw_override = 0;  // PGX_EPW: tuning/diagnostic override of the environments-per-wave heuristic
     if (const char* f = getenv("PGX_EPW")) epw_override = atoi(f);
     // PGX_FLAGS bit1: force the generic (32-bit row mask) observation path
-    e->geo = pgx::step_geometry(cfg->batch, A, e->bmw, e->W, !(e->flags & 2u), epw_override);
+    e->geo = pgx::step_geometry(cfg->batch, A, e->bmw, e->W, !(e->flags & 2u), epw_override,
+                                cfg->obs_dtype == PGX_OBS_U8 ? 1 : 4);
     if (const char* f = getenv("PGX_STAGGER")) e->geo.stagger = atoi(f);  // tuning/diagnostic override
     if (e->geo.lds_bytes > 160 * 1024) {
         const size_t need = e->geo.lds_bytes;

@@ -102,7 +102,7 @@ struct StepGeometry {
     int stagger;      // > 0: odd wave slots sleep this many x 8128 cycles after issuing their loads
     size_t lds_bytes;
 };
-StepGeometry step_geometry(int batch, int A, int bmw, int W, bool allow_p16, int epw_override);
+StepGeometry step_geometry(int batch, int A, int bmw, int W, bool allow_p16, int epw_override, int obs_elem_bytes);
 hipError_t prepare_step(const StepGeometry& g);
 hipError_t launch_step(const StepParams& p, const StepGeometry& g, hipStream_t stream);
 

@@ -821,7 +821,7 @@ static const void* step_fn_for(const StepGeometry& g) {
 
 // G, waves per block, envs per wave, P16 and the LDS footprint for one configuration.
 //   epw_override > 0 forces the number of environments per wave (A <= 32 only; clamped to 64/G).
-StepGeometry step_geometry(int batch, int A, int bmw, int W, bool allow_p16, int epw_override) {
+StepGeometry step_geometry(int batch, int A, int bmw, int W, bool allow_p16, int epw_override, int obs_elem_bytes) {
     StepGeometry g{};
     g.multi_wave = A > 64;
     g.G = 64;
@@ -847,7 +847,7 @@ StepGeometry step_geometry(int batch, int A, int bmw, int W, bool allow_p16, int
     // rounds every odd-slot wave of every round would pay the delay.  PGX_STAGGER overrides (0 = off).
     {
         const long blocks = g.multi_wave ? batch : (batch + g.epw - 1) / g.epw;
-        const size_t stream_bytes = (size_t)g.epw * A * 3 * W * W * 4;
+        const size_t stream_bytes = (size_t)g.epw * A * 3 * W * W * (size_t)obs_elem_bytes;
         g.stagger = (!g.multi_wave && blocks <= 8192 && blocks >= 4096 && stream_bytes >= 32 * 1024 &&
                      (size_t)g.epw * bmw <= 16 * 64) ? 6 : 0;
     }

@@ -12,6 +12,8 @@ from pogema_amd import GridConfig, VecPogema  # noqa: E402
 WL = {"cfg1": (1024, 16, 8, 5), "cfg2": (8192, 64, 64, 5), "cfg3": (8192, 32, 16, 5), "cfg4": (4096, 256, 256, 7),
       "a8big": (65536, 16, 8, 5), "a32": (8192, 32, 32, 5), "a32big": (32768, 32, 32, 5), "a24small": (512, 32, 24, 5), "half": (4096, 64, 64, 5), "three_q": (6144, 64, 64, 5), "quarter": (2048, 64, 64, 5), "eighth": (1024, 64, 64, 5)}
 wl = sys.argv[1]
+u8 = wl.endswith(":u8")
+wl = wl.split(":")[0]
 variants = sys.argv[2:]
 batch, size, agents, r = WL[wl]
 envs = []
@@ -23,7 +25,7 @@ for v in variants:
             k, val = kv.split("=")
             os.environ[k] = val
     env = VecPogema(GridConfig(size=size, num_agents=agents, obs_radius=r, density=0.3, seed=0, collision_system="soft"),
-                    batch=batch, auto_reset=True, reuse_buffers=True)
+                    batch=batch, auto_reset=True, reuse_buffers=True, obs_dtype=torch.uint8 if u8 else torch.float32)
     env.reset(seed=0)
     # every variant writes into the SAME pair of observation buffers: buffer placement alone moves the kernel by up to
     # 10 % (profiles/r1/placement_tiers.txt), which would otherwise drown the effect under test

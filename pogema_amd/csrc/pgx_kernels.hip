@@ -301,6 +301,8 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
         if (MW && tid < MISC_WORDS) s_misc[tid] = 0u;
     }
     lds_sync<MW>();
+    const bool dbg2 = dbg && (p.flags & 64u);  // alternate stamps: [1] loads + staging done, [2] collisions resolved, [3] state phase done
+    if (dbg2 && tid == 0) p.dbg[(size_t)blk * 4 + 1] = wall_clock64();
 
     // ---- phase 2: state update ---------------------------------------------------------------------
     {
@@ -394,6 +396,7 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
                     }
                 }
             }
+            if (dbg2 && tid == 0) p.dbg[(size_t)blk * 4 + 2] = wall_clock64();
             if (!stay) {
                 cur = want;
                 vis = want;
@@ -509,7 +512,7 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
             }
         }
     }
-    if (dbg && tid == 0) p.dbg[(size_t)blk * 4 + 1] = wall_clock64();
+    if (dbg && tid == 0) p.dbg[(size_t)blk * 4 + (dbg2 ? 3 : 1)] = wall_clock64();
     if (!p.obs) return;
     lds_sync<MW>();
 
@@ -574,11 +577,11 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
         const int n = nag * 3 * W * W;
         const size_t base = (size_t)env0 * A * 3 * W * W;
         if (p.obs_u8) {
-            if (dbg && tid == 0) p.dbg[(size_t)blk * 4 + 2] = wall_clock64();
+            if (dbg && !dbg2 && tid == 0) p.dbg[(size_t)blk * 4 + 2] = wall_clock64();
             const int nrows = nag * 3 * W;
             stream_obs_u8(reinterpret_cast<uint8_t*>(p.obs), base, n, W, p.w_magic, tid, NT, (p.flags & 1u) != 0,
                           [&](int row) -> uint32_t { return row < nrows ? (uint32_t)rows16[row] : 0u; });
-            if (dbg && tid == 0) {
+            if (dbg && !dbg2 && tid == 0) {
                 __builtin_amdgcn_s_waitcnt(0);
                 p.dbg[(size_t)blk * 4 + 3] = wall_clock64();
             }
@@ -598,7 +601,7 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
                 out[e] = (float)((rows16[row] >> col) & 1u);
             }
         }
-        if (dbg && tid == 0) p.dbg[(size_t)blk * 4 + 2] = wall_clock64();
+        if (dbg && !dbg2 && tid == 0) p.dbg[(size_t)blk * 4 + 2] = wall_clock64();
         typedef float f32x4 __attribute__((ext_vector_type(4)));
         f32x4* out4 = reinterpret_cast<f32x4*>(out + head);
         const uint32_t* rows32 = smem;
@@ -625,7 +628,7 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
                 row += 1;
             }
         }
-        if (dbg && tid == 0) {
+        if (dbg && !dbg2 && tid == 0) {
             __builtin_amdgcn_s_waitcnt(0);
             p.dbg[(size_t)blk * 4 + 3] = wall_clock64();
         }
@@ -692,7 +695,7 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
                 out[e] = (float)((s_rows[row] >> col) & 1u);
             }
         }
-        if (dbg && tid == 0) p.dbg[(size_t)blk * 4 + 2] = wall_clock64();
+        if (dbg && !dbg2 && tid == 0) p.dbg[(size_t)blk * 4 + 2] = wall_clock64();
         typedef float f32x4 __attribute__((ext_vector_type(4)));
         f32x4* out4 = reinterpret_cast<f32x4*>(out + head);
         for (int q = tid; q < nvec; q += NT) {
@@ -708,7 +711,7 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
             if (p.flags & 1u) __builtin_nontemporal_store(v, &out4[q]);
             else out4[q] = v;
         }
-        if (dbg && tid == 0) {
+        if (dbg && !dbg2 && tid == 0) {
             __builtin_amdgcn_s_waitcnt(0);  // stores retired (vmcnt 0) before the end stamp
             p.dbg[(size_t)blk * 4 + 3] = wall_clock64();
         }

@@ -64,3 +64,66 @@ def test_random_configurations(chunk):
                              obs_dtype=torch.uint8 if c["u8"] else None, **kw)
         assert_rollouts_equal(ref, got, f"fuzz chunk {chunk}: {c}")
         done += 1
+
+
+@pytest.mark.parametrize("chunk", range(3))
+def test_random_device_resets(chunk):
+    """Seeded random sweep of the on-device reset (random maps, shared maps, lifelong tables, masked regeneration)
+    against the plain-C generator oracle."""
+    import ctypes as C
+    from oracle.c_oracle import load
+    from pogema_amd import GridConfig, VecPogema
+    lib = load()
+    lib.po_generate.argtypes = [C.c_int32] * 4 + [C.c_float, C.c_uint64, C.c_int64, C.c_void_p, C.c_int32, C.c_int32,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.po_generate.restype = C.c_int
+    rng = np.random.default_rng(500 + chunk)
+    done = 0
+    while done < 10:
+        S = int(rng.integers(4, 150))
+        density = float(rng.choice([0.0, 0.2, 0.3, 0.45]))
+        free = int(S * S * (1 - density))
+        A = int(rng.integers(1, max(2, min(260, free // 4))))
+        B = int(rng.integers(1, 40)) if S < 64 else int(rng.integers(1, 6))
+        seed, base = int(rng.integers(0, 2 ** 31)), int(rng.integers(0, 5000))
+        on_target = str(rng.choice(["finish", "restart"]))
+        shared = bool(rng.integers(0, 3) == 0)
+        o = np.empty((B, S, S), np.uint8)
+        a = np.empty((B, A, 2), np.int32)
+        t = np.empty((B, A, 2), np.int32)
+        given = None
+        if shared:
+            given = (rng.random((S, S)) < density).astype(np.uint8)
+            o = given.copy()
+        st = lib.po_generate(B, S, S, A, density, 0, seed + base, None, 10, int(shared), o.ctypes.data, a.ctypes.data,
+                             t.ctypes.data)
+        if st != 0:
+            continue
+        gc = GridConfig(map=given.tolist(), num_agents=A, obs_radius=int(rng.integers(1, 6)), seed=seed, on_target=on_target) \
+            if shared else GridConfig(size=S, num_agents=A, obs_radius=int(rng.integers(1, 6)), density=density, seed=seed,
+                                      on_target=on_target)
+        env = VecPogema(gc, batch=B, env_index_base=base)
+        env.reset(seed=seed)
+        state = env.get_state()
+        maps = env._initial[0].cpu().numpy()
+        assert np.array_equal(maps, np.broadcast_to(o, maps.shape) if shared else o), (S, A, B, density, shared)
+        assert np.array_equal(state["agents_xy"].cpu().numpy(), a) and np.array_equal(state["targets_xy"].cpu().numpy(), t)
+        # masked regeneration: generation 1 for a random subset
+        mask = rng.random(B) < 0.5
+        if mask.any():
+            ep = mask.astype(np.uint32)
+            o2 = o.copy()
+            a2, t2 = a.copy(), t.copy()
+            st = lib.po_generate(B, S, S, A, density, 0, seed + base, ep.ctypes.data, 10, int(shared), o2.ctypes.data,
+                                 a2.ctypes.data, t2.ctypes.data)
+            if st == 0:
+                env.reset_where(torch.from_numpy(mask).cuda())
+                s2 = env.get_state()
+                exp_a = np.where(mask[:, None, None], a2, a)
+                exp_t = np.where(mask[:, None, None], t2, t)
+                assert np.array_equal(s2["agents_xy"].cpu().numpy(), exp_a) and np.array_equal(s2["targets_xy"].cpu().numpy(), exp_t)
+                if not shared:
+                    exp_o = np.where(mask[:, None, None], o2, o)
+                    assert np.array_equal(env._initial[0].cpu().numpy(), exp_o)
+        env.close()
+        done += 1

@@ -146,3 +146,35 @@ def test_possible_positions_host_equals_oracle():
     full, _ = place_from_possible(1, 5, pa, pt, 4)  # all four targets are used when A == len(list)
     with pytest.raises(OverflowError):
         place_from_possible(1, 0, pa, pt, 5)
+
+
+def test_host_generator_fuzz_against_oracles():
+    """Random geometries / densities / seeds: host generator == plain-C port == (for the small ones) the literal Python
+    statement of GEN v2, including instances that need several attempts."""
+    from oracle import generator_oracle as G
+    rng = np.random.default_rng(2024)
+    checked_py = 0
+    for _ in range(60):
+        H, W = int(rng.integers(2, 40)), int(rng.integers(2, 40))
+        density = float(rng.choice([0.0, 0.1, 0.3, 0.5, 0.7]))
+        free = int(H * W * (1 - density))
+        if free < 4:
+            continue
+        A = int(rng.integers(1, max(2, min(200, free // 3))))
+        B = int(rng.integers(1, 6))
+        seed = int(rng.integers(0, 2 ** 40))
+        o = np.empty((B, H, W), np.uint8)
+        a = np.empty((B, A, 2), np.int32)
+        t = np.empty((B, A, 2), np.int32)
+        lib = _lib.load()
+        st = lib.pgx_generate(B, H, W, A, C.c_float(density), seed, 6, 2, o.ctypes.data, a.ctypes.data, t.ctypes.data)
+        cst, co, ca, ct = _c_generate(B, H, W, A, density, seed, max_retries=6)
+        assert (st == 0) == (cst == 0), (H, W, A, density, seed)
+        if st != 0:
+            continue
+        assert np.array_equal(o, co) and np.array_equal(a, ca) and np.array_equal(t, ct), (H, W, A, density, seed)
+        if H * W <= 300 and checked_py < 15:
+            ro, ra, rt = G.generate_batch(0, B, H, W, A, density, env_index_base=seed, max_retries=6)
+            assert np.array_equal(o, ro) and np.array_equal(a, ra) and np.array_equal(t, rt)
+            checked_py += 1
+    assert checked_py >= 5

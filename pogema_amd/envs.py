@@ -50,6 +50,8 @@ class Pogema:
         full = 2 * self.grid_config.obs_radius + 1
         self.observation_space = _Box(0.0, 1.0, shape=(3, full, full), dtype=np.float32)
         self.action_space = _Discrete(len(self.grid_config.MOVES))
+        # `GridConfig.persistent` (upstream PersistentWrapper): one engine snapshot per step, `step_back()` restores
+        self._history = [] if self.grid_config.persistent else None
 
     def get_num_agents(self):
         return self.grid_config.num_agents
@@ -73,6 +75,8 @@ class Pogema:
         return [host[i] for i in range(host.shape[0])]
 
     def reset(self, seed: Optional[int] = None, return_info: bool = True, options=None):
+        if self._history is not None:
+            self._history.clear()
         obs, infos = self._vec.reset(seed=seed)
         active = infos["is_active"][0].cpu().numpy()
         out = self._obs_list(obs)
@@ -115,8 +119,19 @@ class Pogema:
         self._io = dict(dev=dev, host=host, views=views, act_host=act_host, act_np=act_host.numpy(), act_dev=act_dev, ptr=ptr)
         return self._io
 
+    def step_back(self) -> bool:
+        """Undo the last step (`PersistentWrapper.step_back`); needs GridConfig(persistent=True)."""
+        if self._history is None:
+            raise RuntimeError("step_back needs GridConfig(persistent=True)")
+        if not self._history:
+            return False
+        self._vec.load_state(self._history.pop())
+        return True
+
     def step(self, action):
         assert len(action) == self.get_num_agents()
+        if self._history is not None:
+            self._history.append(self._vec.save_state())
         import torch
         from . import _lib
         vec = self._vec

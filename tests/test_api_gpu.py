@@ -241,3 +241,21 @@ def test_snapshot_restore_continues_bit_identically(on_target, auto_reset):
         assert torch.equal(v, end_state[k])
     env.close()
     other.close()
+
+
+def test_persistent_step_back():
+    """GridConfig(persistent=True): `step_back()` undoes steps one by one (engine snapshots)."""
+    from pogema_amd import GridConfig, pogema_v0
+    env = pogema_v0(GridConfig(size=8, num_agents=3, obs_radius=2, density=0.1, seed=2, persistent=True))
+    env.reset(seed=2)
+    trail = [env.get_agents_xy()]
+    for acts in ([1, 2, 3], [4, 4, 4], [2, 1, 0]):
+        env.step(acts)
+        trail.append(env.get_agents_xy())
+    assert env.step_back() and env.get_agents_xy() == trail[2]
+    assert env.step_back() and env.get_agents_xy() == trail[1]
+    env.step([4, 4, 4])
+    assert env.get_agents_xy() == trail[2]
+    assert env.step_back() and env.step_back() and env.get_agents_xy() == trail[0]
+    assert env.step_back() is False
+    env.close()

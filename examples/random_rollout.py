@@ -34,7 +34,8 @@ def main():
     episodes = torch.zeros((), dtype=torch.int64, device=env.device)   # everything stays on the device: no per-step sync
     isr_sum = torch.zeros((), device=env.device)
     for _ in range(8):  # warm-up: torch's random/reduction kernels load lazily, the engine probes its output buffers
-        env.step(torch.randint(0, 5, (args.envs, args.agents), device=env.device))
+        _, _, _, _, infos = env.step(torch.randint(0, 5, (args.envs, args.agents), device=env.device))
+        _ = infos["episode_done"].sum() + (infos["metrics"][:, 0] * infos["episode_done"]).sum()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "pgx_internal.h"
 
 namespace pgx {
@@ -439,10 +441,17 @@ hipError_t launch_reset_env(const ResetParams& p, hipStream_t s) {
     const bool lds = reset_forest_in_lds(p.H, p.Wd, p.A);
     const size_t dyn = (lds ? (size_t)p.H * p.Wd * 4 : 0) + (size_t)p.A * 8;
     if (lds) {
-        if (dyn > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&reset_env_kernel<true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-            if (e != hipSuccess) return e;
+        if (dyn > 48 * 1024) {  // opt in once per process (and per device) for the 64 KiB maximum this kernel uses
+            static std::atomic<uint64_t> opted_in{0};
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            const uint64_t bit = 1ull << (dev & 63);
+            if (!(opted_in.load(std::memory_order_relaxed) & bit)) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&reset_env_kernel<true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+                if (e != hipSuccess) return e;
+                opted_in.fetch_or(bit, std::memory_order_relaxed);
+            }
         }
         hipLaunchKernelGGL(reset_env_kernel<true>, dim3(p.env_count), dim3(256), dyn, s, p);
     } else {

@@ -32,6 +32,33 @@ __global__ void fill_chunk_swz(f32x4* __restrict__ out, size_t per_block, int nb
     f32x4* o = out + (size_t)b * per_block;
     for (size_t i = threadIdx.x; i < per_block; i += blockDim.x) store16<MODE>(&o[i], v);
 }
+// chunks handed out per CU: the waves resident on one CU stream ADJACENT chunks (first-come dense CU rank + per-CU
+// ticket), so a CU touches ~3 MB of contiguous address space instead of 32 pages spread over its XCD's eighth
+__global__ void fill_chunk_cu(f32x4* __restrict__ out, size_t per_block, int nblk, unsigned* table, unsigned* tickets,
+                              unsigned* next_rank, unsigned* overflow) {
+    __shared__ unsigned s_chunk;
+    if (threadIdx.x == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_REG_HW_ID, all 32 bits
+        const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));     // HW_REG_XCC_ID[3:0]
+        const unsigned key = (xcc << 8) | ((hw >> 8) & 0xFF);                          // xcc | se,sh,cu bits [15:8]
+        unsigned rank = atomicCAS(&table[key], 0u, 0xFFFFFFFFu);
+        if (rank == 0u) {                      // first wave of this CU: take a dense rank
+            rank = atomicAdd(next_rank, 1u) + 1u;
+            atomicExch(&table[key], rank);
+        } else {
+            while (rank == 0xFFFFFFFFu) rank = atomicAdd(&table[key], 0u);
+        }
+        const unsigned per_cu = (unsigned)nblk / 256u;
+        const unsigned t = atomicAdd(&tickets[rank - 1u], 1u);
+        s_chunk = (rank - 1u < 256u && t < per_cu) ? (rank - 1u) * per_cu + t : 0x80000000u | atomicAdd(overflow, 1u);
+    }
+    __syncthreads();
+    unsigned chunk = s_chunk;
+    if (chunk & 0x80000000u) return;  // microbenchmark only: overflow chunks are dropped (reported by the host)
+    const f32x4 v = {1.f, 0.f, 1.f, 0.f};
+    f32x4* o = out + (size_t)chunk * per_block;
+    for (size_t i = threadIdx.x; i < per_block; i += blockDim.x) o[i] = v;
+}
 template <typename F> static float time_us(F f, int reps) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     f(); CK(hipDeviceSynchronize());
@@ -62,6 +89,17 @@ int main() {
     {
         float t = time_us([&] { hipLaunchKernelGGL(fill_chunk_swz<0>, dim3(8192), dim3(64), 0, 0, a, n / 8192, 8192); }, reps);
         printf("8192 waves x 93KB  XCD-contig  : %7.1f GB/s (%.1f us)\n", bytes / t / 1e3, t);
+    }
+    {
+        unsigned *table, *tickets, *misc;
+        CK(hipMalloc(&table, 4096 * 4)); CK(hipMalloc(&tickets, 1024 * 4)); CK(hipMalloc(&misc, 8));
+        auto run = [&] {
+            hipMemsetAsync(table, 0, 4096 * 4, 0); hipMemsetAsync(tickets, 0, 1024 * 4, 0); hipMemsetAsync(misc, 0, 8, 0);
+            hipLaunchKernelGGL(fill_chunk_cu, dim3(8192), dim3(64), 0, 0, a, n / 8192, 8192, table, tickets, misc, misc + 1);
+        };
+        float t = time_us(run, reps);
+        unsigned h[2]; CK(hipMemcpy(h, misc, 8, hipMemcpyDeviceToHost));
+        printf("8192 waves x 93KB  CU-contig   : %7.1f GB/s (%.1f us)  [CUs seen %u, overflow chunks %u]\n", bytes / t / 1e3, t, h[0], h[1]);
     }
     return 0;
 }

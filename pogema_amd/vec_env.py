@@ -286,8 +286,9 @@ class VecPogema:
     # Placement of the double-buffered observation tensors (reuse_buffers=True).  Equal hipMalloc'd buffers fall into
     # speed tiers on MI355X (~140 / ~144 / ~153 us per configs[2] step on one device, profiles/r1/placement_tiers.txt):
     # where the physical pages live matters.  The engine's placement probe times a plain observation pass into a
-    # handful of candidates; the two fastest are kept, the rest go back to torch's allocator.
-    PLACEMENT_CANDIDATES = 8
+    # set of candidates (up to 32, at most a quarter of the free HBM; ~17 ms once); the two fastest are kept, the rest
+    # go back to torch's allocator.
+    PLACEMENT_CANDIDATES = 32
     PLACEMENT_MIN_BYTES = 64 << 20
 
     def _pick_obs_buffers(self):
@@ -296,7 +297,7 @@ class VecPogema:
         if os.environ.get("PGX_PLACEMENT") == "0":  # diagnostic: take the first two buffers as they come
             n = 2
         free, _ = torch.cuda.mem_get_info(self.device)
-        n = max(2, min(n, int(free * 0.5) // max(obs_bytes, 1)))
+        n = max(2, min(n, int(free * 0.25) // max(obs_bytes, 1)))
         cands = [torch.empty(self.obs_shape, dtype=self.obs_dtype, device=self.device) for _ in range(n)]
         if n == 2 or not self._has_state():
             return cands[:2]

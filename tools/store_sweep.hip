@@ -32,6 +32,16 @@ __global__ void fill_chunk_swz(f32x4* __restrict__ out, size_t per_block, int nb
     f32x4* o = out + (size_t)b * per_block;
     for (size_t i = threadIdx.x; i < per_block; i += blockDim.x) store16<MODE>(&o[i], v);
 }
+// XCD x owns groups of `g` consecutive chunks, groups interleaved over the 8 XCDs (g = 1: identity mapping; g = nblk / 8:
+// the XCD-contiguous mapping)
+template <int MODE>
+__global__ void fill_chunk_group(f32x4* __restrict__ out, size_t per_block, int g) {
+    const f32x4 v = {1.f, 0.f, 1.f, 0.f};
+    const int x = blockIdx.x & 7, i = blockIdx.x >> 3;
+    const int b = ((i / g) * 8 + x) * g + (i % g);
+    f32x4* o = out + (size_t)b * per_block;
+    for (size_t k = threadIdx.x; k < per_block; k += blockDim.x) store16<MODE>(&o[k], v);
+}
 // chunks handed out per CU: the waves resident on one CU stream ADJACENT chunks (first-come dense CU rank + per-CU
 // ticket), so a CU touches ~3 MB of contiguous address space instead of 32 pages spread over its XCD's eighth
 __global__ void fill_chunk_cu(f32x4* __restrict__ out, size_t per_block, int nblk, unsigned* table, unsigned* tickets,
@@ -89,6 +99,10 @@ int main() {
     {
         float t = time_us([&] { hipLaunchKernelGGL(fill_chunk_swz<0>, dim3(8192), dim3(64), 0, 0, a, n / 8192, 8192); }, reps);
         printf("8192 waves x 93KB  XCD-contig  : %7.1f GB/s (%.1f us)\n", bytes / t / 1e3, t);
+    }
+    for (int g : {1, 4, 16, 64, 256, 1024}) {
+        float t = time_us([&] { hipLaunchKernelGGL(fill_chunk_group<0>, dim3(8192), dim3(64), 0, 0, a, n / 8192, g); }, reps);
+        printf("8192 waves x 93KB  XCD groups of %4d chunks : %7.1f GB/s (%.1f us)\n", g, bytes / t / 1e3, t);
     }
     {
         unsigned *table, *tickets, *misc;

@@ -293,20 +293,28 @@ class VecPogema:
 
     def _pick_obs_buffers(self):
         obs_bytes = int(np.prod(self.obs_shape)) * (4 if self.obs_dtype == torch.float32 else 1)
-        n = self.PLACEMENT_CANDIDATES if obs_bytes >= self.PLACEMENT_MIN_BYTES else 2
+        batch_n = self.PLACEMENT_CANDIDATES if obs_bytes >= self.PLACEMENT_MIN_BYTES else 2
         if os.environ.get("PGX_PLACEMENT") == "0":  # diagnostic: take the first two buffers as they come
-            n = 2
+            batch_n = 2
         free, _ = torch.cuda.mem_get_info(self.device)
-        n = max(2, min(n, int(free * 0.25) // max(obs_bytes, 1)))
-        cands = [torch.empty(self.obs_shape, dtype=self.obs_dtype, device=self.device) for _ in range(n)]
-        if n == 2 or not self._has_state():
-            return cands[:2]
+        budget = max(2, int(free * 0.25) // max(obs_bytes, 1))   # candidates alive at once
+        new = lambda k: [torch.empty(self.obs_shape, dtype=self.obs_dtype, device=self.device) for _ in range(k)]
+        if batch_n == 2 or not self._has_state():
+            return new(2)
         timed = []
         us = C.c_float()
-        for t in cands:
-            _lib.check(self._lib.pgx_time_observe(self._handle, t.data_ptr(), 3, C.byref(us), self._stream()))
-            timed.append((float(us.value), t))
-        timed.sort(key=lambda x: x[0])
+        # Fast placements are rare on some devices (1-2 of 32): keep drawing batches while the runner-up is clearly
+        # slower than the best and the memory budget allows; all candidates stay alive meanwhile so that the allocator
+        # cannot hand the same region out twice.
+        while len(timed) < budget:
+            for t in new(min(batch_n, budget - len(timed))):
+                _lib.check(self._lib.pgx_time_observe(self._handle, t.data_ptr(), 3, C.byref(us), self._stream()))
+                timed.append((float(us.value), t))
+            timed.sort(key=lambda x: x[0])
+            if len(timed) >= 2 and timed[1][0] <= 1.03 * timed[0][0]:
+                break
+            if len(timed) >= 3 * batch_n:
+                break
         self.placement_us = [round(u, 2) for u, _ in timed]
         return [timed[0][1], timed[1][1]]
 

@@ -134,8 +134,10 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
     int epw_override = 0;  // PGX_EPW: tuning/diagnostic override of the environments-per-wave heuristic
     if (const char* f = getenv("PGX_EPW")) epw_override = atoi(f);
     // PGX_FLAGS bit1: force the generic (32-bit row mask) observation path
+    int waves_override = 0;  // PGX_WAVES: 1 = single-wave kernel for A <= 64 whatever the launch size, k = k helper waves
+    if (const char* f = getenv("PGX_WAVES")) waves_override = atoi(f);
     e->geo = pgx::step_geometry(cfg->batch, A, e->bmw, e->W, !(e->flags & 2u), epw_override,
-                                cfg->obs_dtype == PGX_OBS_U8 ? 1 : 4);
+                                cfg->obs_dtype == PGX_OBS_U8 ? 1 : 4, waves_override);
     if (const char* f = getenv("PGX_STAGGER")) e->geo.stagger = atoi(f);  // tuning/diagnostic override
     if (e->geo.lds_bytes > 160 * 1024) {
         const size_t need = e->geo.lds_bytes;

@@ -95,14 +95,15 @@ struct StepParams {
 // How one configuration maps onto the step kernel (pgx_kernels.hip: step_geometry()).
 struct StepGeometry {
     int G;            // lanes per environment group (power of two, 64 when multi_wave)
-    int waves;        // waves per workgroup: 1, or ceil(A / 64) when num_agents > 64
+    int waves;        // waves per workgroup: 1, ceil(A / 64) when num_agents > 64, or 2..8 helper waves (small launches)
     int epw;          // environments per wave (1 when multi_wave)
     bool multi_wave;  // num_agents > 64: one environment per workgroup
     bool p16;         // window side <= 16: packed 16-bit row masks aliased over the LDS state
     int stagger;      // > 0: odd wave slots sleep this many x 8128 cycles after issuing their loads
     size_t lds_bytes;
 };
-StepGeometry step_geometry(int batch, int A, int bmw, int W, bool allow_p16, int epw_override, int obs_elem_bytes);
+StepGeometry step_geometry(int batch, int A, int bmw, int W, bool allow_p16, int epw_override, int obs_elem_bytes,
+                           int waves_override);
 hipError_t prepare_step(const StepGeometry& g);
 hipError_t launch_step(const StepParams& p, const StepGeometry& g, hipStream_t stream);
 

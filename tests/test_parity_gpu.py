@@ -175,3 +175,26 @@ def test_rotation_cycles(A):
             assert_rollouts_equal(ref, got, f"rotation A={A} {collision}")
             moved = (ref["agents_xy"][0, 0] != agents[0]).any(axis=1)
             assert moved.all() if collision == "soft" else not moved.any()
+
+
+HELPER_GEOMS = [g for g in GEOMETRIES if g[0] in ("baseline_cfg1", "dense_small", "full_wave", "odd_agents", "one_agent", "wide_window")]
+
+
+@pytest.mark.parametrize("waves", [1, 2, 4, 8])
+@pytest.mark.parametrize("geom", HELPER_GEOMS, ids=[g[0] for g in HELPER_GEOMS])
+def test_helper_waves(geom, waves, monkeypatch):
+    """num_agents <= 64 on the multi-wave kernel (helper waves that only share the observation write; chosen
+    automatically for small launches of large environments) and, with PGX_WAVES=1, the same geometries forced onto the
+    single-wave kernel: both against the oracle, all collision systems, float32 and uint8 observations."""
+    import torch
+    monkeypatch.setenv("PGX_WAVES", str(waves))
+    name, B, H, Wd, A, r, density, T, max_steps = geom
+    seed = zlib.crc32(f"helpers/{name}".encode()) % (2 ** 31)
+    obstacles, agents, targets = generate_instances(B, H, Wd, A, density, seed)
+    actions = random_actions(T, B, A, seed + 1)
+    for collision, on_target, u8 in (("priority", "finish", False), ("soft", "restart", True), ("block_both", "nothing", False)):
+        kw = dict(obs_radius=r, collision_system=collision, on_target=on_target, max_episode_steps=max_steps,
+                  auto_reset=True, seed=3, env_index_base=5)
+        ref = oracle_rollout(obstacles, agents, targets, actions, **kw)
+        got = engine_rollout(obstacles, agents, targets, actions, obs_dtype=torch.uint8 if u8 else None, **kw)
+        assert_rollouts_equal(ref, got, f"helpers={waves}/{name}/{collision}/{on_target}")

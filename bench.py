@@ -198,7 +198,11 @@ def main():
                                    f"{agents} agents, obs_radius {r}, density {args.density}",
                        "collision_system": args.collision, "on_target": args.on_target, "auto_reset": args.auto_reset,
                        "max_episode_steps": args.max_episode_steps, "obs_dtype": args.obs_dtype,
-                       "action_dtype": args.action_dtype, "envs_per_gpu": batch, "sharding": f"batch-sharded x{world}, no collective"},
+                       "action_dtype": args.action_dtype, "envs_per_gpu": batch, "sharding": f"batch-sharded x{world}, no collective",
+                       "obs_buffers": (f"2 alternating buffers, the fastest of {len(env.placement_us)} placement-probed "
+                                       f"candidates (observation pass {env.placement_us[0]:.1f} / {env.placement_us[1]:.1f} us; "
+                                       f"slowest candidate {env.placement_us[-1]:.1f} us)")
+                                      if getattr(env, "placement_us", None) else "2 alternating buffers"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "pgx::step_kernel", "kernel_ms": kernel_ms,

@@ -196,6 +196,24 @@ class Pogema:
         return {"obstacles": self.get_obstacles(), "agents_xy": self.get_agents_xy(), "targets_xy": self.get_targets_xy(),
                 "is_active": [bool(v) for v in st["is_active"][0].cpu().numpy()], "elapsed": int(st["elapsed"][0])}
 
+    def render(self, mode: str = "ansi"):
+        """Text rendering of the current state (upstream `pogema/utils.py: render_grid`, console view): '#' obstacle,
+        '.' free, lowercase letter = agent, the same letter in uppercase = its target ('*' agent standing on its own
+        target; hidden/finished agents are not drawn).  Returns the string (and prints it when mode == 'human')."""
+        obstacles = self.get_obstacles()
+        st = self.get_state()
+        rows = [["#" if v else "." for v in row] for row in obstacles]
+        names = "abcdefghijklmnopqrstuvwxyz"
+        for i, (tx, ty) in enumerate(st["targets_xy"]):
+            rows[tx][ty] = names[i % 26].upper()
+        for i, ((x, y), active) in enumerate(zip(st["agents_xy"], st["is_active"])):
+            if active:
+                rows[x][y] = "*" if (x, y) == tuple(st["targets_xy"][i]) else names[i % 26]
+        text = "\n".join("".join(r) for r in rows)
+        if mode == "human":
+            print(text)
+        return text
+
     def close(self):
         self._vec.close()
 

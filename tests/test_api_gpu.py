@@ -259,3 +259,13 @@ def test_persistent_step_back():
     assert env.step_back() and env.step_back() and env.get_agents_xy() == trail[0]
     assert env.step_back() is False
     env.close()
+
+
+def test_text_render():
+    from pogema_amd import GridConfig, pogema_v0
+    env = pogema_v0(GridConfig(map="a.#\n..B\nbA.", obs_radius=1))
+    env.reset()
+    assert env.render() == "a.#\n..B\nbA."
+    env.step([2, 0])  # agent a moves down
+    assert env.render() == "..#\na.B\nbA."
+    env.close()

@@ -48,7 +48,7 @@ def _instances(c):
 
 @pytest.mark.parametrize("chunk", range(8))
 def test_random_configurations(chunk):
-    rng = np.random.default_rng(1000 + chunk)
+    rng = np.random.default_rng(int(__import__('os').environ.get('PGX_FUZZ_SEED', '1000')) + chunk)
     done = 0
     while done < 12:
         c = _random_case(rng)
@@ -77,7 +77,7 @@ def test_random_device_resets(chunk):
     lib.po_generate.argtypes = [C.c_int32] * 4 + [C.c_float, C.c_uint64, C.c_int64, C.c_void_p, C.c_int32, C.c_int32,
                                                  C.c_void_p, C.c_void_p, C.c_void_p]
     lib.po_generate.restype = C.c_int
-    rng = np.random.default_rng(500 + chunk)
+    rng = np.random.default_rng(int(__import__('os').environ.get('PGX_FUZZ_SEED', '1000')) // 2 + chunk)
     done = 0
     while done < 10:
         S = int(rng.integers(4, 150))

@@ -1,21 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X-native POGEMA step engine.
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py --gpus N --steps K --warmup W [--windows 5] [--workload cfg2] [--global-batch G]
 
-A "step" is one pass of the hot path (`VecPogema.step` -> pgx_step -> one HIP kernel launch) over one
-batch of synthetic input: BASELINE.json configs[2] -- 8192 envs per GPU, 64x64 maps, 64 agents,
-obs_radius 5, density 0.3, random-obstacle maps, uniform random actions already resident in HBM.
-Metric: agent-steps/sec, whole job = n_gpus * batch * agents * K / max-over-ranks wall time.
-The batch shards over GPUs with no data-path collective (weak scaling); torch.distributed is used
-for the start barrier and the max-over-ranks clock only.
+A "step" is one pass of the hot path (`VecPogema.step` -> pgx_step -> one HIP kernel launch) over one batch of
+synthetic input: BASELINE.json configs[2] by default -- 8192 envs per GPU, 64x64 maps, 64 agents, obs_radius 5,
+density 0.3, random-obstacle maps, uniform random actions already resident in HBM.
+Metric: agent-steps/sec, whole job = (envs over all ranks) * agents * K / max-over-ranks wall time of K steps.
+
+Launch contract:
+  * under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` every process is one rank
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment); WORLD_SIZE must equal --gpus;
+  * `python bench.py --gpus N` with N > 1 and no WORLD_SIZE starts the N ranks ITSELF (one child process per device,
+    before this process touches the GPU) and fails loudly when the box has fewer than N devices -- it never prints a
+    line whose n_gpus differs from --gpus;
+  * the batch shards over the ranks with no data-path collective; torch.distributed (RCCL) carries the barriers, the
+    max-over-ranks clock and the per-rank kernel times only.
+Timing: W warm-up steps, then `--windows` windows of EXACTLY K steps each, every window bracketed by barrier +
+torch.cuda.synchronize() on both sides and reduced with MAX over ranks; `value` comes from the MEDIAN window (a single
+20-step window is 2.6 ms of GPU time -- one lucky or unlucky sample), all windows are listed in the line.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -26,24 +38,29 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 WORKLOADS = {
-    # name: (batch per GPU, size, agents, obs_radius)  -- BASELINE.json configs[1..4]
+    # name: (envs per GPU, size, agents, obs_radius)  -- BASELINE.json configs[1..4]
     "cfg1": (1024, 16, 8, 5),
     "cfg2": (8192, 64, 64, 5),
-    "cfg3": (8192, 32, 16, 5),   # configs[3]: 65536 envs over 8 GPUs = 8192 per GPU
+    "cfg3": (8192, 32, 16, 5),   # configs[3]: 65536 envs over 8 GPUs (`--global-batch 65536`) = 8192 per GPU
     "cfg4": (4096, 256, 256, 7),
 }
 
 
-def algorithmic_bytes_per_agent_step(size: int, agents: int, r: int, obs_bytes: int = 4) -> float:
-    """12*W^2 obs + 3*ceil(P^2/8)/A bitmaps + 21 bytes of per-agent state/IO
-    (3 * obs_bytes * W^2 for the observation when the non-drop-in uint8 mode is benchmarked)."""
+def algorithmic_bytes_per_agent_step(size: int, agents: int, r: int, obs_bytes: int = 4, action_bytes: int = 1) -> float:
+    """12*W^2 obs + 3*ceil(P^2/8)/A bitmaps + 21 bytes of per-agent state/IO, of which
+    1 byte is the int8 action (3 * obs_bytes * W^2 for the observation when the non-drop-in uint8 mode is benchmarked;
+    wider action dtypes are budgeted at their real width)."""
     W, P = 2 * r + 1, size + 2 * r
-    return 3.0 * obs_bytes * W * W + 3.0 * ((P * P + 7) // 8) / agents + 21.0
+    return 3.0 * obs_bytes * W * W + 3.0 * ((P * P + 7) // 8) / agents + 20.0 + action_bytes
 
 
-def cpu_baseline(size, agents, r, collision, density, max_steps, target_seconds=12.0):
-    """Times the plain-C oracle port (oracle/, kind 'port') on the host cores on a bounded sample of
-    the same workload.  Reported next to the GPU number; never the thing being measured."""
+# ----------------------------------------------------------------------------------------------------------
+# CPU baselines (rank 0, N = 1 only): the oracle is the thing being timed here, never the product path
+# ----------------------------------------------------------------------------------------------------------
+def cpu_baseline(size, agents, r, collision, density, max_steps, target_seconds=12.0, python_seconds=4.0):
+    """Times the plain-C oracle port (oracle/, kind 'port') on the host cores on a bounded sample of the same
+    workload, plus the pure-Python literal oracle (closest in spirit to the reference's per-agent Python loops) on a
+    smaller sample.  Reported next to the GPU number; never the thing being measured."""
     import numpy as np
     from oracle.c_oracle import COracle
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -85,98 +102,296 @@ def cpu_baseline(size, agents, r, collision, density, max_steps, target_seconds=
         if dt >= target_seconds or steps >= 200000:
             break
     env.close()
-    return {"value": B * agents * steps / dt, "unit": "agent-steps/s", "cores": cores, "kind": "port",
+    line = {"value": B * agents * steps / dt, "unit": "agent-steps/s", "cores": cores, "kind": "port",
             "single_core_value": single, "host_cores_available": avail,
             "sample": f"{B} envs x {agents} agents x {steps} steps of the same workload ({size}x{size}, r={r}, "
                       f"{collision}), plain-C oracle port with OpenMP over envs, {dt:.1f} s wall"}
+    # pure-Python literal oracle: one env at a time, dicts and per-agent numpy slices like the reference
+    from oracle.pogema_oracle import PogemaOracle
+    nb = 2
+    penvs = [PogemaOracle(obstacles[b], agents_xy[b], targets_xy[b], obs_radius=r, collision_system=collision,
+                          on_target="finish", max_episode_steps=max_steps, auto_reset=True) for b in range(nb)]
+    psteps = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < python_seconds:
+        for b, e in enumerate(penvs):
+            e.step(pool[psteps % 16][b])
+        psteps += 1
+    pdt = time.perf_counter() - t0
+    line["python_literal"] = {"value": nb * agents * psteps / pdt, "unit": "agent-steps/s", "cores": 1, "kind": "port",
+                              "sample": f"{nb} envs x {agents} agents x {psteps} steps, pure-Python literal oracle "
+                                        f"(dicts + per-agent numpy slices), {pdt:.1f} s wall"}
+    return line
 
 
-def main():
+# ----------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without torchrun
+# ----------------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def visible_device_count() -> int:
+    """Number of HIP devices WITHOUT initialising the GPU in this process (the launcher must not: its children own
+    the devices).  torch.cuda.device_count() only enumerates on this image."""
+    import torch
+    return int(torch.cuda.device_count())
+
+
+def launch_ranks(n: int, argv, stub: bool = False) -> int:
+    """Start `n` rank processes of this script (RANK = LOCAL_RANK = 0..n-1, rendezvous on 127.0.0.1) and wait for
+    them.  Returns the worst exit code.  Rank 0's stdout (the JSON line) is passed through."""
+    if not stub:
+        have = visible_device_count()
+        if have < n:
+            print(f"bench.py: --gpus {n} requested but this box exposes {have} HIP device(s); refusing to print a "
+                  f"line for fewer GPUs than asked", file=sys.stderr)
+            return 2
+    port = _free_port()
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), PGX_BENCH_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if rank == 0 else subprocess.DEVNULL))
+    worst = 0
+    deadline = time.time() + float(os.environ.get("PGX_BENCH_TIMEOUT", "1800"))
+    for p in procs:
+        try:
+            rc = p.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()  # exactly the child we started
+            rc = 124
+        worst = max(worst, abs(rc))
+    if worst:
+        print(f"bench.py: a rank exited with code {worst}", file=sys.stderr)
+    return worst
+
+
+# ----------------------------------------------------------------------------------------------------------
+# the step under test
+# ----------------------------------------------------------------------------------------------------------
+class EngineStep:
+    """The product path: VecPogema on this rank's device."""
+
+    def __init__(self, args, rank, device, batch, env_base, size, agents, r, placement_probe=True):
+        import torch
+        from pogema_amd import GridConfig, VecPogema
+        self.torch = torch
+        gc = GridConfig(size=size, density=args.density, num_agents=agents, obs_radius=r, seed=0,
+                        collision_system=args.collision, on_target=args.on_target,
+                        max_episode_steps=args.max_episode_steps)
+        self.env = VecPogema(gc, batch=batch, device=device, env_index_base=env_base,
+                             auto_reset=True if args.auto_reset == "restore" else "regenerate", reuse_buffers=True,
+                             obs_dtype=torch.float32 if args.obs_dtype == "float32" else torch.uint8,
+                             placement_probe=placement_probe)
+        self.env.reset(seed=0)
+        tdt = {"int8": torch.int8, "int32": torch.int32, "int64": torch.int64}[args.action_dtype]
+        gen = torch.Generator(device=device)
+        gen.manual_seed(1 + rank)
+        self.pool = [torch.randint(0, 5, (batch, agents), generator=gen, device=device).to(tdt) for _ in range(32)]
+        self.no_obs = args.no_obs
+        self.graph = None
+        self.graph_len = 0
+        self.i = 0
+        if args.graph > 0:
+            self._capture(args.graph)
+
+    def _capture(self, n):
+        """`--graph n`: n consecutive steps (n kernel launches, alternating output buffers, n different action
+        tensors) captured in one HIP graph -- removes the host launch cost between the short kernels of configs[1]."""
+        torch = self.torch
+        for k in range(4):
+            self.env.step(self.pool[k % len(self.pool)], compute_obs=not self.no_obs)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for k in range(n):
+                self.env.step(self.pool[k % len(self.pool)], compute_obs=not self.no_obs)
+        self.graph, self.graph_len = g, n
+
+    def run(self, steps):
+        if self.graph is not None:
+            for _ in range(steps // self.graph_len):
+                self.graph.replay()
+            return
+        for _ in range(steps):
+            self.env.step(self.pool[self.i % len(self.pool)], compute_obs=not self.no_obs)
+            self.i += 1
+
+    def describe_buffers(self):
+        pu = getattr(self.env, "placement_us", None)
+        if pu:
+            return (f"2 alternating buffers, the fastest of {len(pu)} placement-probed candidates (observation pass "
+                    f"{pu[0]:.1f} / {pu[1]:.1f} us; slowest candidate {pu[-1]:.1f} us)")
+        return "2 alternating buffers as the allocator returned them (no placement probe)"
+
+    def close(self):
+        self.env.close()
+
+
+class StubStep:
+    """TEST ONLY (`--stub`): no GPU, no engine -- a fixed host sleep per step so that tests/test_bench_launch.py can
+    drive the launcher, the barriers, the max-over-ranks reduction and the JSON contract on CPU over gloo.  A line
+    produced this way says data = "stub" and is not a measurement."""
+
+    def __init__(self, rank):
+        self.delay = 0.0005 * (1 + rank)
+
+    def run(self, steps):
+        time.sleep(self.delay * steps)
+
+    def describe_buffers(self):
+        return "stub"
+
+    def close(self):
+        pass
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--windows", type=int, default=5, help="timed windows of exactly --steps steps; value = median window")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--collision", default="soft", choices=["priority", "block_both", "soft"])
     ap.add_argument("--on-target", default="finish", choices=["finish", "restart", "nothing"])
-    ap.add_argument("--batch", type=int, default=0, help="override envs per GPU")
+    ap.add_argument("--batch", type=int, default=0, help="override envs per GPU (weak scaling)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="total envs over all ranks, sharded with sharding.shard_bounds (strong scaling); "
+                         "configs[3] = --workload cfg3 --global-batch 65536 on 8 GPUs")
     ap.add_argument("--density", type=float, default=0.3)
     ap.add_argument("--max-episode-steps", type=int, default=64)
-    ap.add_argument("--action-dtype", default="int64", choices=["int8", "int32", "int64"])
+    ap.add_argument("--action-dtype", default="int8", choices=["int8", "int32", "int64"],
+                    help="int8 = the 1 byte/agent of SURVEY 8(d)'s formula; wider dtypes are budgeted at their width")
     ap.add_argument("--obs-dtype", default="float32", choices=["float32", "uint8"],
                     help="float32 = the reference's dtype (the headline); uint8 = the engine's lighter non-drop-in mode")
     ap.add_argument("--auto-reset", default="restore", choices=["restore", "regenerate"],
                     help="restore = finished envs return to their initial state inside the step kernel (headline); "
                          "regenerate = they get a fresh random instance on the device (pgx_regenerate)")
+    ap.add_argument("--graph", type=int, default=0, help="capture this many steps in one HIP graph and replay it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-default-placement", action="store_true",
+                    help="skip the extra window that times the unprobed (default allocator) buffers")
     ap.add_argument("--no-obs", action="store_true", help="diagnostic: skip the observation write")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    args = ap.parse_args()
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)  # tests only, see StubStep
+    args = ap.parse_args(argv)
+    if args.gpus < 1 or args.steps < 1 or args.windows < 1:
+        raise SystemExit("--gpus, --steps and --windows must be >= 1")
+    if args.graph > 0 and args.steps % args.graph:
+        raise SystemExit(f"--steps {args.steps} must be a multiple of --graph {args.graph}")
+
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None:
+        if args.gpus > 1:  # launcher role: start the ranks before anything touches the GPU, pass the verdict on
+            raise SystemExit(launch_ranks(args.gpus, sys.argv[1:] if argv is None else list(argv), stub=args.stub))
+        world, rank, local_rank = 1, 0, 0
+    else:
+        world, rank, local_rank = int(world_env), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+        if world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; they must agree")
 
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device; there is no CPU fallback for the product path")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+    if args.stub:
+        device = torch.device("cpu")
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device; there is no CPU fallback for the product path")
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"bench.py: rank {rank} wants device {local_rank}, the box has {torch.cuda.device_count()}")
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", device_id=device)
 
-    from pogema_amd import GridConfig, VecPogema
+    from pogema_amd.sharding import shard_bounds
+    per_gpu, size, agents, r = WORKLOADS[args.workload]
+    if args.global_batch > 0:
+        env_base, batch = shard_bounds(args.global_batch, world, rank)
+        total_envs, scaling = args.global_batch, "strong"
+    else:
+        batch = args.batch if args.batch > 0 else per_gpu
+        env_base, total_envs, scaling = rank * batch, world * batch, "weak"
+    if batch < 1:
+        raise SystemExit(f"rank {rank} holds no environment (global batch {args.global_batch} over {world} ranks)")
 
-    batch, size, agents, r = WORKLOADS[args.workload]
-    if args.batch > 0:
-        batch = args.batch
-    gc = GridConfig(size=size, density=args.density, num_agents=agents, obs_radius=r, seed=0,
-                    collision_system=args.collision, on_target=args.on_target,
-                    max_episode_steps=args.max_episode_steps)
-    env = VecPogema(gc, batch=batch, device=device, env_index_base=rank * batch,
-                    auto_reset=True if args.auto_reset == "restore" else "regenerate", reuse_buffers=True,
-                    obs_dtype=torch.float32 if args.obs_dtype == "float32" else torch.uint8)
-    env.reset(seed=0)
-    tdt = {"int8": torch.int8, "int32": torch.int32, "int64": torch.int64}[args.action_dtype]
-    gen = torch.Generator(device=device)
-    gen.manual_seed(1 + rank)
-    pool = [torch.randint(0, 5, (batch, agents), generator=gen, device=device).to(tdt) for _ in range(32)]
+    def sync():
+        if not args.stub:
+            torch.cuda.synchronize(device)
 
     def barrier():
-        torch.cuda.synchronize(device)
+        sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(device)
+        sync()
 
-    for i in range(args.warmup):
-        env.step(pool[i % len(pool)], compute_obs=not args.no_obs)
-    barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()  # same (current) stream the engine launches on
-    for i in range(args.steps):
-        env.step(pool[i % len(pool)], compute_obs=not args.no_obs)
-    ev1.record()
-    torch.cuda.synchronize(device)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(device)
-    elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # avg launch-to-launch duration on the stream
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    def reduce_max(x: float) -> float:
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
+
+    def timed_windows(step, n_windows):
+        """-> (wall seconds per window, max over ranks; this rank's stream-side ms per step per window)"""
+        walls, kernel = [], []
+        for _ in range(n_windows):
+            barrier()
+            if not args.stub:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()  # the (current) stream the engine launches on
+            t0 = time.perf_counter()
+            step.run(args.steps)
+            if not args.stub:
+                ev1.record()
+            barrier()
+            dt = time.perf_counter() - t0
+            walls.append(reduce_max(dt))
+            kernel.append(ev0.elapsed_time(ev1) / args.steps if not args.stub else dt / args.steps * 1e3)
+        return walls, kernel
+
+    # the default-allocator placement first, in a fresh address space (before the probe's candidates exist)
+    default_ms = None
+    if not args.stub and not args.no_default_placement and world == 1:
+        plain = EngineStep(args, rank, device, batch, env_base, size, agents, r, placement_probe=False)
+        plain.run(max(args.warmup, 4))
+        _, k = timed_windows(plain, 1)
+        default_ms = k[0]
+        plain.close()
+        del plain
+        torch.cuda.empty_cache()
+
+    step = StubStep(rank) if args.stub else EngineStep(args, rank, device, batch, env_base, size, agents, r)
+    warm = args.warmup if args.graph <= 0 else -(-args.warmup // args.graph) * args.graph
+    if warm:
+        step.run(warm)
+    walls, kernel = timed_windows(step, args.windows)
+    elapsed = statistics.median(walls)
+    kernel_ms = statistics.median(kernel)
+    per_rank_kernel = [kernel_ms]
+    if world > 1:
+        t = torch.tensor([kernel_ms], dtype=torch.float64, device=device)
+        parts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        per_rank_kernel = [float(p.item()) for p in parts]
 
     if rank == 0:
-        n_agent_steps = world * batch * agents * args.steps
+        n_agent_steps = total_envs * agents * args.steps
         value = n_agent_steps / elapsed
-        bpas = algorithmic_bytes_per_agent_step(size, agents, r, 4 if args.obs_dtype == "float32" else 1)
-        alg_bytes = bpas * batch * agents  # per launch (one GPU)
+        abytes = {"int8": 1, "int32": 4, "int64": 8}[args.action_dtype]
+        bpas = algorithmic_bytes_per_agent_step(size, agents, r, 4 if args.obs_dtype == "float32" else 1, abytes)
+        alg_bytes = bpas * batch * agents  # per launch (this GPU's shard)
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -187,33 +402,39 @@ def main():
                     traffic = json.load(f).get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        headline = args.workload == "cfg2" and args.obs_dtype == "float32" and not args.stub
         line = {
-            "metric": "agent-steps/sec (whole node), 64-agent 64x64 grid, batch=8192 envs"
-                      if (args.workload == "cfg2" and args.obs_dtype == "float32")
-                      else f"agent-steps/sec (whole node), workload {args.workload}, obs {args.obs_dtype}",
+            "metric": "agent-steps/sec (whole node), 64-agent 64x64 grid, batch=8192 envs" if headline
+                      else f"{'STUB (not a measurement) ' if args.stub else ''}agent-steps/sec (whole node), "
+                           f"workload {args.workload}, obs {args.obs_dtype}",
             "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[{args.workload[-1]}]: {batch} envs/GPU, {size}x{size} map, "
-                                   f"{agents} agents, obs_radius {r}, density {args.density}",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
+            "vs_baseline": None, "dtype": "u32", "data": "stub" if args.stub else "synthetic",
+            "windows": {"n": args.windows, "statistic": "median", "steps_each": args.steps,
+                        "ms_per_step": [w / args.steps * 1e3 for w in walls]},
+            "config": {"workload": f"BASELINE.json configs[{args.workload[-1]}]: {total_envs} envs over {world} GPU(s) "
+                                   f"({batch} on rank 0), {size}x{size} map, {agents} agents, obs_radius {r}, "
+                                   f"density {args.density}",
                        "collision_system": args.collision, "on_target": args.on_target, "auto_reset": args.auto_reset,
                        "max_episode_steps": args.max_episode_steps, "obs_dtype": args.obs_dtype,
-                       "action_dtype": args.action_dtype, "envs_per_gpu": batch, "sharding": f"batch-sharded x{world}, no collective",
-                       "obs_buffers": (f"2 alternating buffers, the fastest of {len(env.placement_us)} placement-probed "
-                                       f"candidates (observation pass {env.placement_us[0]:.1f} / {env.placement_us[1]:.1f} us; "
-                                       f"slowest candidate {env.placement_us[-1]:.1f} us)")
-                                      if getattr(env, "placement_us", None) else "2 alternating buffers"},
+                       "action_dtype": args.action_dtype, "envs_per_gpu": batch, "global_batch": total_envs,
+                       "sharding": f"batch-sharded x{world}, no collective",
+                       "launch": f"hipGraph of {args.graph} steps" if args.graph > 0 else "one pgx_step launch per step",
+                       "obs_buffers": step.describe_buffers()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "pgx::step_kernel", "kernel_ms": kernel_ms,
+                         "kernel": "pgx::step_kernel", "kernel_ms": kernel_ms, "kernel_ms_per_rank": per_rank_kernel,
+                         "kernel_ms_windows": kernel,
+                         "default_placement_kernel_ms": default_ms,
                          "algorithmic_bytes_per_agent_step": bpas, "algorithmic_bytes_per_launch": alg_bytes},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.stub:
             line["cpu_baseline"] = cpu_baseline(size, agents, r, args.collision, args.density, args.max_episode_steps,
                                                 args.cpu_seconds)
         print(json.dumps(line), flush=True)
-    env.close()
+    step.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

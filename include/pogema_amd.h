@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PGX_ABI_VERSION 2
+#define PGX_ABI_VERSION 3
 
 /* error codes */
 #define PGX_OK 0
@@ -49,6 +49,19 @@ extern "C" {
 #define PGX_ON_TARGET_FINISH 0
 #define PGX_ON_TARGET_RESTART 1
 #define PGX_ON_TARGET_NOTHING 2
+
+/* Switches for the semantics the builder recalls with LOW confidence (docs/SPEC.md open questions Q1, Q4, Q7; the
+ * reference source is not mounted, /root/reference/README.md:3,5).  Value 0 is always the recalled-literal default;
+ * the other value is the plausible alternative, so that pinning against the real package is a config flip, not a
+ * kernel edit.  Every variant is implemented in the step kernel and in both oracles and covered by the parity matrix. */
+#define PGX_SOFT_LOWEST_INDEX_WINS 0 /* Q1: `soft`, several movers claim one free/vacated cell: the lowest index moves
+                                        (literal `used_cells[cell].remove(agent)` + reverse-index loop)               */
+#define PGX_SOFT_ALL_STAY 1          /* Q1 alternative: every claimant of a contested cell stays (textbook MAPF)       */
+#define PGX_COOP_REWARD_ALL_SOLVED 0 /* Q4: on_target = NOTHING pays 1.0 to every agent iff ALL are on their goals    */
+#define PGX_COOP_REWARD_PER_AGENT 1  /* Q4 alternative: 1.0 to each agent standing on its own goal in this step        */
+#define PGX_BAD_ACTION_NOOP 0        /* Q7: an action outside 0..4 is a noop                                           */
+#define PGX_BAD_ACTION_FLAG 1        /* Q7 alternative: still a noop on the device, but counted -- pgx_bad_action_count()
+                                        lets the host raise the reference's IndexError                               */
 
 /* dtype of the `actions` buffer handed to pgx_step */
 #define PGX_ACTION_I8 0
@@ -87,6 +100,10 @@ typedef struct pgx_config {
                                /*    (`empty_outside=False`; the stream is this build's own, keyed by      */
                                /*    seed, global env index and the env's generation counter)             */
     float outside_density;
+    int32_t soft_vertex_rule;  /* PGX_SOFT_*        (0 = recalled literal algorithm)                    */
+    int32_t coop_reward;       /* PGX_COOP_REWARD_* (0 = recalled)                                       */
+    int32_t bad_action;        /* PGX_BAD_ACTION_*  (0 = noop)                                           */
+    int32_t reserved0;
 } pgx_config;
 
 typedef struct pgx_env pgx_env; /* opaque */
@@ -121,7 +138,8 @@ int pgx_reset_from_state(pgx_env* env, const uint8_t* obstacles, const int32_t* 
  * 4-connected component) -- SURVEY L1 / section 8f rank 2 -- plus, for on_target = RESTART, the component
  * tables `PogemaLifeLong` draws new targets from.  The random stream is this build's own counter-based
  * generator (numpy's PCG64 is not reproduced -- DESIGN.md); pgx_generate draws the SAME instances on the
- * host.  Env i of the shard draws instance (seed + env_index_base + i).
+ * host.  Env i of the shard draws instance (seed, env_index_base + i): seed and global env index are separate key
+ * components (hashed one after the other), so batches reset with different seeds share no instance.
  *   shared_map  device u8 [height, width] or NULL   given map for every env (GridConfig.map): only
  *                                                   starts/targets are drawn, `density` is ignored
  *   env_mask    device u8 [batch] or NULL           NULL: every env, generation 0 (a pure function of
@@ -162,6 +180,12 @@ int pgx_get_map(pgx_env* env, uint8_t* obstacles, void* stream);
  *   is_active    device u8  [batch, agents]   infos[i]['is_active'] after the step      may be NULL */
 int pgx_step(pgx_env* env, const void* actions, int action_dtype, void* obs, float* rewards,
              uint8_t* terminated, uint8_t* truncated, uint8_t* is_active, void* stream);
+
+/* Number of out-of-range actions (outside 0..4) that ACTIVE agents submitted since the last call (bad_action =
+ * PGX_BAD_ACTION_FLAG only; otherwise always 0).  Inactive agents' actions are never looked at, as in the reference's
+ * `if self.grid.is_active[agent_idx]` guards.  Synchronises `stream`, then clears the counter.  The host side turns a
+ * non-zero count into the reference's IndexError (`MOVES[action]`). */
+int64_t pgx_bad_action_count(pgx_env* env, void* stream);
 
 /* Episode metrics, fused into pgx_step.  Replaces the metric wrappers of upstream pogema/wrappers/metrics.py
  * (ISR / CSR / ep_length / SoC / makespan, their non-disappearing forms for on_target = NOTHING, and
@@ -210,19 +234,20 @@ int pgx_load_snapshot(pgx_env* env, const void* blob, void* stream);
 /* Fills host buffers with `batch` random solvable instances: Bernoulli(density) obstacles, starts and
  * targets on distinct free cells with each start/target pair in one 4-connected component.
  * Plays the role of upstream pogema/generator.py at reset; the random stream is this
- * build's own (numpy's PCG64 sequence is not reproduced -- DESIGN.md).  Env i uses seed0 + i.
+ * build's own (numpy's PCG64 sequence is not reproduced -- DESIGN.md).  Env i draws instance
+ * (seed0, env_index_base + i) -- the same one pgx_reset_random draws for that seed and global index.
  *   obstacles host u8 [batch, height, width]; agent_xy / target_xy host i32 [batch, agents, 2]
  * nthreads <= 0 picks the number of online cores.  Returns PGX_E_PLACEMENT if an env cannot be
  * filled after `max_retries` re-draws. */
 int pgx_generate(int32_t batch, int32_t height, int32_t width, int32_t num_agents, float density,
-                 uint64_t seed0, int32_t max_retries, int32_t nthreads, uint8_t* obstacles,
-                 int32_t* agent_xy, int32_t* target_xy);
+                 uint64_t seed0, int64_t env_index_base, int32_t max_retries, int32_t nthreads,
+                 uint8_t* obstacles, int32_t* agent_xy, int32_t* target_xy);
 
 /* Same placement on GIVEN obstacle maps (custom `GridConfig.map`): only starts/targets are drawn.
  *   obstacles host u8 [batch, height, width], or [height, width] when shared_map != 0. */
 int pgx_place_agents(int32_t batch, int32_t height, int32_t width, int32_t num_agents, uint64_t seed0,
-                     int32_t max_retries, int32_t nthreads, const uint8_t* obstacles, int32_t shared_map,
-                     int32_t* agent_xy, int32_t* target_xy);
+                     int64_t env_index_base, int32_t max_retries, int32_t nthreads, const uint8_t* obstacles,
+                     int32_t shared_map, int32_t* agent_xy, int32_t* target_xy);
 
 #ifdef __cplusplus
 }

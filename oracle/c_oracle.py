@@ -13,6 +13,9 @@ LIB_PATH = os.path.join(_HERE, "libpogema_oracle.so")
 
 COLLISION = {"priority": 0, "block_both": 1, "soft": 2}
 ON_TARGET = {"finish": 0, "restart": 1, "nothing": 2}
+SOFT_VERTEX_RULE = {"lowest_index": 0, "all_stay": 1}
+COOP_REWARD = {"all_solved": 0, "per_agent": 1}
+BAD_ACTION = {"noop": 0, "flag": 1}
 
 
 class PoConfig(C.Structure):
@@ -20,7 +23,8 @@ class PoConfig(C.Structure):
                 ("obs_radius", C.c_int32), ("collision_system", C.c_int32), ("on_target", C.c_int32),
                 ("max_episode_steps", C.c_int32), ("auto_reset", C.c_int32), ("reserved0", C.c_int32),
                 ("seed", C.c_uint64), ("env_index_base", C.c_int64), ("random_outside", C.c_int32),
-                ("outside_density", C.c_float)]
+                ("outside_density", C.c_float), ("soft_vertex_rule", C.c_int32), ("coop_reward", C.c_int32),
+                ("bad_action", C.c_int32), ("reserved1", C.c_int32)]
 
 
 _lib = None
@@ -42,6 +46,8 @@ def load(build_if_missing: bool = True):
     lib.po_reset.argtypes = [vp, vp, vp, vp]
     lib.po_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int]
     lib.po_observe.argtypes = [vp, vp]
+    lib.po_bad_action_count.argtypes = [vp]
+    lib.po_bad_action_count.restype = C.c_int64
     lib.po_get_state.argtypes = [vp, vp, vp, vp, vp, vp]
     _lib = lib
     return lib
@@ -52,13 +58,14 @@ class COracle:
 
     def __init__(self, batch, height, width, num_agents, obs_radius, collision_system="priority", on_target="finish",
                  max_episode_steps=64, auto_reset=False, seed=0, env_index_base=0, empty_outside=True,
-                 outside_density=0.0):
+                 outside_density=0.0, soft_vertex_rule="lowest_index", coop_reward="all_solved", bad_action="noop"):
         self.lib = load()
         self.B, self.H, self.Wd, self.A, self.r = batch, height, width, num_agents, obs_radius
         self.W = 2 * obs_radius + 1
         cfg = PoConfig(batch, height, width, num_agents, obs_radius, COLLISION[collision_system], ON_TARGET[on_target],
                        max_episode_steps, int(auto_reset), 0, seed, env_index_base, 0 if empty_outside else 1,
-                       float(outside_density))
+                       float(outside_density), SOFT_VERTEX_RULE[soft_vertex_rule], COOP_REWARD[coop_reward],
+                       BAD_ACTION[bad_action], 0)
         self.h = self.lib.po_create(C.byref(cfg))
         if not self.h:
             raise MemoryError("po_create failed")
@@ -98,6 +105,10 @@ class COracle:
                          term.ctypes.data, trunc.ctypes.data, act.ctypes.data, self.metrics.ctypes.data,
                          self.episode_done.ctypes.data, int(nthreads))
         return obs, rew, term.astype(bool), trunc.astype(bool), act.astype(bool)
+
+    def bad_action_count(self):
+        """Out-of-range actions of active agents since the last call (bad_action='flag' only)."""
+        return int(self.lib.po_bad_action_count(self.h))
 
     def get_state(self, occupancy=False):
         a = np.empty((self.B, self.A, 2), np.int32)

@@ -31,6 +31,11 @@ typedef struct po_config {
     int64_t env_index_base;
     int32_t random_outside;   /* empty_outside=False: Bernoulli(outside_density) obstacles beyond the ring */
     float outside_density;
+    /* switches for the low-confidence recollections (docs/SPEC.md Q1 / Q4 / Q7); 0 = recalled default */
+    int32_t soft_vertex_rule; /* 0 lowest index wins a contested cell (literal remove + reverse loop), 1 all claimants stay */
+    int32_t coop_reward;      /* 0 1.0 to all iff all on goal, 1 1.0 to each agent on its own goal */
+    int32_t bad_action;       /* 0 out-of-range action = noop, 1 noop + counted (po_bad_action_count) */
+    int32_t reserved1;
 } po_config;
 
 typedef struct po_env {
@@ -55,6 +60,7 @@ typedef struct po_env {
     int32_t* comp_begin;   /* [B][H*W] */
     int32_t* comp_len;     /* [B][H*W] */
     int32_t* comp_cells;   /* [B][H*W] unpadded cell index, grouped by component, row-major inside */
+    int64_t bad_actions;   /* out-of-range actions of active agents since the last po_bad_action_count() */
 } po_env;
 
 static const int MOVE_DX[5] = {0, -1, 1, 0, 0};
@@ -235,6 +241,9 @@ typedef struct scratch {
     int32_t* touched;       /* cells to clear afterwards                                         */
     int ntouched;
     int8_t* acts;           /* mutable copy of the actions                                       */
+    int32_t* who;           /* all_stay: active agent standing on the cell, -1 = nobody         */
+    int32_t* revert;        /* all_stay: agents reverted in the current round                  */
+    int64_t* clean;         /* actions with out-of-range values replaced by noop                */
 } scratch;
 
 static scratch* scratch_new(size_t P, int A) {
@@ -247,10 +256,14 @@ static scratch* scratch_new(size_t P, int A) {
     s->elist = (int32_t*)malloc(sizeof(int32_t) * P * 5 * 2);
     s->touched = (int32_t*)malloc(sizeof(int32_t) * (size_t)(A + 1) * 8);
     s->acts = (int8_t*)malloc((size_t)A);
+    s->who = (int32_t*)malloc(sizeof(int32_t) * P);
+    for (size_t k = 0; k < P; ++k) s->who[k] = -1;
+    s->revert = (int32_t*)malloc(sizeof(int32_t) * (size_t)(A + 1));
+    s->clean = (int64_t*)malloc(sizeof(int64_t) * (size_t)(A + 1));
     return s;
 }
 static void scratch_free(scratch* s) {
-    free(s->mark); free(s->ccnt); free(s->clist); free(s->ecnt); free(s->elist); free(s->touched); free(s->acts); free(s);
+    free(s->mark); free(s->ccnt); free(s->clist); free(s->ecnt); free(s->elist); free(s->touched); free(s->acts); free(s->who); free(s->revert); free(s->clean); free(s);
 }
 static void touch(scratch* s, int cell) { s->touched[s->ntouched++] = cell; }
 
@@ -314,6 +327,53 @@ static void move_agents(po_env* e, int b, const int64_t* actions, scratch* s) {
             if (s->mark[d] != 2) grid_move(e, b, i, a);
         }
         for (int k = 0; k < s->ntouched; ++k) s->mark[s->touched[k]] = 0;
+    } else if (e->c.soft_vertex_rule == 1) {
+        /* docs/SPEC.md Q1 alternative (textbook MAPF): synchronous fixed point -- every round reverts ALL movers whose
+         * destination is an obstacle, is claimed by anybody else (a non-mover claims its own cell) or lies across a
+         * swapped edge; repeat until nothing changes; apply the surviving moves. */
+        for (int i = 0; i < A; ++i) s->acts[i] = (int8_t)actions[i];
+        for (int i = 0; i < A; ++i)
+            if (e->active[base + i]) s->who[e->px[base + i] * PW + e->py[base + i]] = i;
+        for (int changed = 1; changed;) {
+            changed = 0;
+            s->ntouched = 0;
+            for (int i = 0; i < A; ++i) {
+                if (!e->active[base + i]) continue;
+                const int a = s->acts[i];
+                const int d = (e->px[base + i] + MOVE_DX[a]) * PW + (e->py[base + i] + MOVE_DY[a]);
+                if (s->ccnt[d] == 0) touch(s, d);
+                if (s->ccnt[d] < 255) s->ccnt[d]++;
+            }
+            int nrev = 0;
+            for (int i = 0; i < A; ++i) {
+                if (!e->active[base + i] || s->acts[i] == 0) continue;
+                const int a = s->acts[i];
+                const int c = e->px[base + i] * PW + e->py[base + i];
+                const int d = (e->px[base + i] + MOVE_DX[a]) * PW + (e->py[base + i] + MOVE_DY[a]);
+                const int ow = s->who[d];
+                int swap = 0;
+                if (ow >= 0 && s->acts[ow] != 0) {
+                    const int ao = s->acts[ow];
+                    swap = (e->px[base + ow] + MOVE_DX[ao]) * PW + (e->py[base + ow] + MOVE_DY[ao]) == c;
+                }
+                if (o[d] || s->ccnt[d] > 1 || swap) s->revert[nrev++] = i;
+            }
+            for (int k = 0; k < nrev; ++k) { s->acts[s->revert[k]] = 0; changed = 1; }
+            for (int k = 0; k < s->ntouched; ++k) s->ccnt[s->touched[k]] = 0;
+        }
+        for (int i = 0; i < A; ++i)
+            if (e->active[base + i]) {
+                const int c = e->px[base + i] * PW + e->py[base + i];
+                s->who[c] = -1;
+                occ[c] = 0;
+            }
+        for (int i = 0; i < A; ++i) {
+            if (!e->active[base + i]) continue;
+            const int a = s->acts[i];
+            e->px[base + i] += MOVE_DX[a];
+            e->py[base + i] += MOVE_DY[a];
+            occ[(size_t)e->px[base + i] * PW + e->py[base + i]] = 1;
+        }
     } else {
         s->ntouched = 0;
         for (int i = 0; i < A; ++i) s->acts[i] = (int8_t)actions[i];
@@ -423,7 +483,19 @@ static void step_env(po_env* e, int b, const int64_t* actions, float* obs, float
     const size_t base = (size_t)b * A;
     const size_t P = (size_t)e->PH * e->PW;
     uint8_t* occ = e->occ + (size_t)b * P;
-    move_agents(e, b, actions + base, s);
+    /* docs/SPEC.md Q7: out-of-range actions are noops; counted for ACTIVE agents when bad_action = flag */
+    int64_t* clean = s->clean;
+    int bad = 0;
+    for (int i = 0; i < A; ++i) {
+        int64_t a = actions[base + i];
+        if (a < 0 || a > 4) { bad += e->active[base + i] ? 1 : 0; a = 0; }
+        clean[i] = a;
+    }
+    if (bad && e->c.bad_action == 1) {
+#pragma omp atomic
+        e->bad_actions += bad;
+    }
+    move_agents(e, b, clean, s);
     int all_term = 1;
     int n_arrived = 0;  /* was_on_goal: on goal and still active right after the moves */
     for (int i = 0; i < A; ++i) {
@@ -467,7 +539,12 @@ static void step_env(po_env* e, int b, const int64_t* actions, float* obs, float
             const size_t g = base + i;
             solved = solved && e->active[g] && e->px[g] == e->fx[g] && e->py[g] == e->fy[g];
         }
-        for (int i = 0; i < A; ++i) { rewards[base + i] = solved ? 1.0f : 0.0f; terminated[base + i] = (uint8_t)solved; }
+        for (int i = 0; i < A; ++i) {
+            const size_t g = base + i;
+            const int mine = e->active[g] && e->px[g] == e->fx[g] && e->py[g] == e->fy[g];
+            rewards[g] = (e->c.coop_reward == 1 ? mine : solved) ? 1.0f : 0.0f;
+            terminated[g] = (uint8_t)solved;
+        }
     }
     for (int i = 0; i < A; ++i) {
         all_term = all_term && terminated[base + i];
@@ -498,6 +575,12 @@ int po_step(po_env* e, const int64_t* actions, float* obs, float* rewards, uint8
         scratch_free(s);
     }
     return 0;
+}
+
+int64_t po_bad_action_count(po_env* e) {
+    const int64_t n = e->bad_actions;
+    e->bad_actions = 0;
+    return n;
 }
 
 int po_observe(po_env* e, float* obs) {

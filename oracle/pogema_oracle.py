@@ -30,6 +30,10 @@ MOVES = ((0, 0), (-1, 0), (1, 0), (0, -1), (0, 1))
 
 COLLISION_SYSTEMS = ("priority", "block_both", "soft")
 ON_TARGET = ("finish", "restart", "nothing")
+# Switches for the low-confidence recollections (docs/SPEC.md Q1 / Q4 / Q7); the first value is the recalled default.
+SOFT_VERTEX_RULES = ("lowest_index", "all_stay")
+COOP_REWARDS = ("all_solved", "per_agent")
+BAD_ACTIONS = ("noop", "flag")
 
 _MASK32 = 0xFFFFFFFF
 TAG_OUTSIDE = 0x4F55545300000000  # 'OUTS'
@@ -192,8 +196,11 @@ class PogemaOracle:
 
     def __init__(self, obstacles, agents_xy, targets_xy, obs_radius=5, collision_system="priority",
                  on_target="finish", max_episode_steps=64, auto_reset=False, seed=0, env_index=0,
-                 empty_outside=True, outside_density=0.0, epoch=0):
+                 empty_outside=True, outside_density=0.0, epoch=0, soft_vertex_rule="lowest_index",
+                 coop_reward="all_solved", bad_action="noop"):
         assert collision_system in COLLISION_SYSTEMS and on_target in ON_TARGET
+        assert soft_vertex_rule in SOFT_VERTEX_RULES and coop_reward in COOP_REWARDS and bad_action in BAD_ACTIONS
+        self.soft_vertex_rule, self.coop_reward, self.bad_action = soft_vertex_rule, coop_reward, bad_action
         self._init_args = (np.array(obstacles, copy=True), [tuple(map(int, p)) for p in agents_xy],
                            [tuple(map(int, p)) for p in targets_xy])
         self.obs_radius = int(obs_radius)
@@ -271,7 +278,46 @@ class PogemaOracle:
                     dx, dy = MOVES[actions[i]]
                     if used_cells.get((x + dx, y + dy), None) != "blocked":
                         g.move(i, actions[i])
-        else:  # soft
+        elif self.soft_vertex_rule == "all_stay":
+            # docs/SPEC.md Q1 alternative -- the textbook MAPF rule, stated as a synchronous (Jacobi) fixed point:
+            # in every round ALL movers whose destination is an obstacle, is claimed by anybody else (a non-mover
+            # claims the cell it stands on) or lies across a swapped edge are reverted to noop at once; repeat
+            # until nothing changes; then the surviving moves are applied.
+            actions = list(actions)
+            agents_xy = list(g.positions_xy)
+            standing = {agents_xy[i]: i for i in range(n) if g.is_active[i]}
+            changed = True
+            while changed:
+                changed = False
+                dest = {}
+                claims = {}
+                for i, (x, y) in enumerate(agents_xy):
+                    if g.is_active[i]:
+                        dx, dy = MOVES[actions[i]]
+                        dest[i] = (x + dx, y + dy)
+                        claims.setdefault(dest[i], []).append(i)
+                revert = []
+                for i in range(n):
+                    if g.is_active[i] and actions[i] != 0:
+                        d = dest[i]
+                        o = standing.get(d)
+                        swap = o is not None and actions[o] != 0 and dest[o] == agents_xy[i]
+                        if g.has_obstacle(*d) or len(claims[d]) > 1 or swap:
+                            revert.append(i)
+                for i in revert:
+                    actions[i] = 0
+                    changed = True
+            for i in range(n):
+                if g.is_active[i]:
+                    x, y = g.positions_xy[i]
+                    g.positions[x, y] = FREE
+            for i in range(n):
+                if g.is_active[i]:
+                    x, y = g.positions_xy[i]
+                    dx, dy = MOVES[actions[i]]
+                    g.positions_xy[i] = (x + dx, y + dy)
+                    g.positions[x + dx, y + dy] = OBSTACLE
+        else:  # soft, recalled literal algorithm (lowest index wins a contested cell)
             actions = list(actions)
             used_cells = {}
             used_edges = {}
@@ -316,6 +362,14 @@ class PogemaOracle:
         assert len(actions) == self.num_agents
         g = self.grid
         n = self.num_agents
+        # docs/SPEC.md Q7: the reference indexes MOVES[action] for ACTIVE agents only.  'noop': out-of-range actions
+        # do nothing; 'flag': they raise the reference's IndexError (negative values included -- Python's
+        # wrap-around of MOVES[-1] is deliberately not reproduced).
+        for i, a in enumerate(actions):
+            if not 0 <= a <= 4:
+                if self.bad_action == "flag" and g.is_active[i]:
+                    raise IndexError(f"action {a} of agent {i} is outside 0..4")
+                actions[i] = 0
         self.move_agents(actions)
         # `was_on_goal` of the reference: on goal and still active right after the moves
         was_on_goal = [bool(g.on_goal(i) and g.is_active[i]) for i in range(n)]
@@ -339,7 +393,10 @@ class PogemaOracle:
             terminated = [False] * n
         else:  # nothing (cooperative finish)
             solved = all(g.on_goal(i) and g.is_active[i] for i in range(n))
-            rewards = [1.0 if solved else 0.0] * n
+            if self.coop_reward == "all_solved":
+                rewards = [1.0 if solved else 0.0] * n
+            else:  # docs/SPEC.md Q4 alternative: each agent is paid for standing on its own goal
+                rewards = [1.0 if (g.on_goal(i) and g.is_active[i]) else 0.0 for i in range(n)]
             terminated = [bool(solved)] * n
         infos = [{"is_active": bool(g.is_active[i])} for i in range(n)]
         truncated = [False] * n

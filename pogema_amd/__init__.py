@@ -5,7 +5,9 @@ from .grid_config import (GridConfig, Easy8x8, Normal8x8, Hard8x8, Easy16x16, Ha
 
 __version__ = "0.1.0"
 
-__all__ = ["GridConfig", "VecPogema", "Pogema", "pogema_v0", "Easy8x8", "Normal8x8", "Hard8x8", "Easy16x16",
+from .semantics import Semantics
+
+__all__ = ["GridConfig", "Semantics", "VecPogema", "Pogema", "pogema_v0", "Easy8x8", "Normal8x8", "Hard8x8", "Easy16x16",
            "Hard16x16", "Easy32x32", "Hard32x32", "Easy64x64", "Hard64x64"]
 
 

@@ -12,11 +12,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PGX_LIB: diagnostic override (A/B of two builds of the SAME engine on one box); never a fallback
 LIB_PATH = os.environ.get("PGX_LIB") or os.path.join(_HERE, "libpogema_amd.so")
 
-PGX_ABI_VERSION = 2
+PGX_ABI_VERSION = 3
 
 COLLISION_SYSTEMS = {"priority": 0, "block_both": 1, "soft": 2}
 ON_TARGET = {"finish": 0, "restart": 1, "nothing": 2}
 ACTION_DTYPES = {"int8": 0, "int32": 1, "int64": 2}
+SOFT_VERTEX_RULES = {"lowest_index": 0, "all_stay": 1}
+COOP_REWARDS = {"all_solved": 0, "per_agent": 1}
+BAD_ACTIONS = {"noop": 0, "flag": 1}
 def _obs_dtypes():
     import torch
     return {torch.float32: 0, torch.uint8: 1}
@@ -45,7 +48,7 @@ METRIC_NAMES = ("ISR", "CSR", "ep_length", "SoC", "makespan", "avg_throughput")
 EXPORTED_SYMBOLS = (
     "pgx_abi_version", "pgx_last_error", "pgx_create", "pgx_destroy", "pgx_obs_elems", "pgx_agent_elems",
     "pgx_reset_from_state", "pgx_reset_random", "pgx_regenerate", "pgx_regenerate_failures", "pgx_get_map", "pgx_step", "pgx_observe", "pgx_set_metrics_buffers", "pgx_get_state", "pgx_generate", "pgx_place_agents",
-    "pgx_snapshot_bytes", "pgx_save_snapshot", "pgx_load_snapshot", "pgx_time_observe",
+    "pgx_snapshot_bytes", "pgx_save_snapshot", "pgx_load_snapshot", "pgx_time_observe", "pgx_bad_action_count",
 )
 
 
@@ -62,6 +65,7 @@ class PgxConfig(C.Structure):
         ("max_episode_steps", C.c_int32), ("auto_reset", C.c_int32), ("obs_dtype", C.c_int32),
         ("seed", C.c_uint64), ("env_index_base", C.c_int64),
         ("random_outside", C.c_int32), ("outside_density", C.c_float),
+        ("soft_vertex_rule", C.c_int32), ("coop_reward", C.c_int32), ("bad_action", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -100,6 +104,8 @@ def load() -> C.CDLL:
     lib.pgx_regenerate_failures.argtypes = [vp, vp]
     lib.pgx_regenerate_failures.restype = i64
     lib.pgx_get_map.argtypes = [vp, vp, vp]
+    lib.pgx_bad_action_count.argtypes = [vp, vp]
+    lib.pgx_bad_action_count.restype = i64
     lib.pgx_time_observe.argtypes = [vp, vp, i32, C.POINTER(C.c_float), vp]
     lib.pgx_time_observe.restype = C.c_int
     lib.pgx_snapshot_bytes.argtypes = [vp]
@@ -111,8 +117,8 @@ def load() -> C.CDLL:
     lib.pgx_observe.argtypes = [vp, vp, vp]
     lib.pgx_set_metrics_buffers.argtypes = [vp, vp, vp]
     lib.pgx_get_state.argtypes = [vp, vp, vp, vp, vp, vp, vp]
-    lib.pgx_generate.argtypes = [i32, i32, i32, i32, f32, u64, i32, i32, vp, vp, vp]
-    lib.pgx_place_agents.argtypes = [i32, i32, i32, i32, u64, i32, i32, vp, i32, vp, vp]
+    lib.pgx_generate.argtypes = [i32, i32, i32, i32, f32, u64, i64, i32, i32, vp, vp, vp]
+    lib.pgx_place_agents.argtypes = [i32, i32, i32, i32, u64, i64, i32, i32, vp, i32, vp, vp]
     for name in ("pgx_create", "pgx_destroy", "pgx_reset_from_state", "pgx_reset_random", "pgx_regenerate", "pgx_get_map",
                  "pgx_step", "pgx_observe", "pgx_set_metrics_buffers", "pgx_set_metrics_buffers",
                  "pgx_get_state", "pgx_generate", "pgx_place_agents"):

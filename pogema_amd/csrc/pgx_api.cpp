@@ -87,6 +87,7 @@ struct pgx_env {
     uint32_t* epoch = nullptr;            // [B]
     uint32_t* fail_count = nullptr;       // [1]
     uint32_t* regen_fail = nullptr;       // [1] sticky failure counter of pgx_regenerate
+    uint32_t* bad_count = nullptr;        // [1] out-of-range actions (bad_action = FLAG)
     uint32_t *labels = nullptr, *pending = nullptr;  // [chunk_envs][H*W], allocated on first use
     uint8_t* scratch_map = nullptr;       // [chunk_envs][H*W] draft maps
     int chunk_envs = 0;
@@ -115,6 +116,10 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
     if (cfg->on_target < 0 || cfg->on_target > 2) return fail(PGX_E_INVALID, "unknown on_target %d", cfg->on_target);
     if (cfg->random_outside && !(cfg->outside_density >= 0.0f && cfg->outside_density <= 1.0f))
         return fail(PGX_E_INVALID, "outside_density %.3f outside [0, 1]", (double)cfg->outside_density);
+    if (cfg->soft_vertex_rule < 0 || cfg->soft_vertex_rule > 1 || cfg->coop_reward < 0 || cfg->coop_reward > 1 ||
+        cfg->bad_action < 0 || cfg->bad_action > 1)
+        return fail(PGX_E_INVALID, "unknown semantics switch (soft_vertex_rule %d, coop_reward %d, bad_action %d)",
+                    cfg->soft_vertex_rule, cfg->coop_reward, cfg->bad_action);
     if (cfg->obs_dtype != PGX_OBS_F32 && cfg->obs_dtype != PGX_OBS_U8)
         return fail(PGX_E_INVALID, "unknown obs_dtype %d", cfg->obs_dtype);
     if ((int64_t)cfg->num_agents > (int64_t)cfg->height * cfg->width)
@@ -172,6 +177,7 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
     alloc((void**)&e->epoch, B * sizeof(uint32_t));
     alloc((void**)&e->fail_count, sizeof(uint32_t));
     alloc((void**)&e->regen_fail, sizeof(uint32_t));
+    alloc((void**)&e->bad_count, sizeof(uint32_t));
     if (cfg->on_target == PGX_ON_TARGET_RESTART) {
         const size_t cells = B * (size_t)cfg->height * cfg->width;
         alloc((void**)&e->comp_begin, cells * sizeof(uint32_t));
@@ -185,6 +191,7 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
         return fail(err == hipErrorOutOfMemory ? PGX_E_NOMEM : PGX_E_HIP, "hipMalloc failed: %s", msg);
     }
     err = hipMemset(e->regen_fail, 0, sizeof(uint32_t));
+    if (err == hipSuccess) err = hipMemset(e->bad_count, 0, sizeof(uint32_t));
     if (err == hipSuccess) err = pgx::prepare_step(e->geo);
     if (err != hipSuccess) {
         const char* msg = hipGetErrorString(err);
@@ -206,7 +213,7 @@ int pgx_destroy(pgx_env* e) {
     DeviceGuard guard(e->device);
     void* ptrs[] = {e->obst,   e->pos,     e->tgt,        e->pos0,     e->tgt0,       e->active,
                     e->elapsed, e->comp_begin, e->comp_len, e->comp_cells, e->tcount, e->dbg, e->macc,
-                    e->map_u8, e->todo, e->regen, e->epoch, e->fail_count, e->regen_fail, e->labels, e->pending,
+                    e->map_u8, e->todo, e->regen, e->epoch, e->fail_count, e->regen_fail, e->bad_count, e->labels, e->pending,
                     e->scratch_map};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -332,7 +339,8 @@ int pgx_reset_random(pgx_env* e, float density, uint64_t seed, const uint8_t* sh
     pgx::ResetParams p = reset_params(e);
     p.max_retries = max_retries;
     p.thr = pgx::gen_density_threshold(density);
-    p.key_base = seed + (uint64_t)c.env_index_base;  // env i draws instance (seed + global index)
+    p.gen_seed = seed;  // env i draws instance (seed, env_index_base + i): two key components, hashed separately
+    p.env_index_base = c.env_index_base;
     p.shared_map = shared_map;
     PGX_HIP(pgx::launch_reset_begin(env_mask, e->todo, e->regen, e->epoch, c.batch, s));
     PGX_HIP(hipMemsetAsync(e->fail_count, 0, sizeof(uint32_t), s));
@@ -368,7 +376,8 @@ int pgx_regenerate(pgx_env* e, const uint8_t* env_mask, float density, uint64_t 
     pgx::ResetParams p = reset_params(e);
     p.max_retries = max_retries;
     p.thr = pgx::gen_density_threshold(density);
-    p.key_base = seed + (uint64_t)c.env_index_base;
+    p.gen_seed = seed;
+    p.env_index_base = c.env_index_base;
     p.shared_map = shared_map;
     p.fail_count = e->regen_fail;
     p.env_begin = 0;
@@ -497,6 +506,10 @@ static void fill_params(const pgx_env* e, pgx::StepParams& p) {
     p.epw = e->geo.epw;
     p.stagger = e->geo.stagger;
     p.obs_u8 = e->cfg.obs_dtype == PGX_OBS_U8 ? 1 : 0;
+    p.soft_rule = c.soft_vertex_rule;
+    p.coop_reward = c.coop_reward;
+    p.bad_action = c.bad_action;
+    p.bad_count = e->bad_count;
     p.seed = c.seed;
     p.env_index_base = c.env_index_base;
     p.obst = e->obst;
@@ -535,6 +548,18 @@ int pgx_step(pgx_env* e, const void* actions, int action_dtype, void* obs, float
     p.act_out = is_active;
     PGX_HIP(pgx::launch_step(p, e->geo, (hipStream_t)stream));
     return PGX_OK;
+}
+
+int64_t pgx_bad_action_count(pgx_env* e, void* stream) {
+    if (!e) return fail(PGX_E_INVALID, "pgx_bad_action_count: null handle");
+    DeviceGuard guard(e->device);
+    if (guard.err != hipSuccess) return fail(PGX_E_HIP, "cannot select device: %s", hipGetErrorString(guard.err));
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t n = 0;
+    PGX_HIP(hipMemcpyAsync(&n, e->bad_count, sizeof n, hipMemcpyDeviceToHost, s));
+    PGX_HIP(hipStreamSynchronize(s));
+    if (n) PGX_HIP(hipMemsetAsync(e->bad_count, 0, sizeof n, s));
+    return (int64_t)n;
 }
 
 int pgx_set_metrics_buffers(pgx_env* e, float* metrics, uint8_t* episode_done) {
@@ -701,7 +726,8 @@ inline uint64_t instance_hash(uint64_t seed, uint64_t env, uint32_t epoch, uint3
 }  // namespace
 
 int pgx_generate(int32_t batch, int32_t height, int32_t width, int32_t num_agents, float density, uint64_t seed0,
-                 int32_t max_retries, int32_t nthreads, uint8_t* obstacles, int32_t* agent_xy, int32_t* target_xy) {
+                 int64_t env_index_base, int32_t max_retries, int32_t nthreads, uint8_t* obstacles, int32_t* agent_xy,
+                 int32_t* target_xy) {
     if (batch < 1 || height < 1 || width < 1 || num_agents < 1 || !obstacles || !agent_xy || !target_xy)
         return fail(PGX_E_INVALID, "pgx_generate: bad argument");
     if (!(density >= 0.0f && density <= 1.0f)) return fail(PGX_E_INVALID, "density %.3f outside [0, 1]", (double)density);
@@ -721,9 +747,9 @@ int pgx_generate(int32_t batch, int32_t height, int32_t width, int32_t num_agent
             for (int64_t b = t; b < batch; b += nt) {
                 bool ok = false;
                 for (int attempt = 0; attempt < max_retries && !ok; ++attempt) {
-                    // env b of a batch seeded seed0 is global env (seed0 + b) of stream 0, so shards and
-                    // single-env calls draw the same instances (seed + env_index_base + i in VecPogema)
-                    const uint64_t h = instance_hash(0, seed0 + (uint64_t)b, 0, (uint32_t)attempt);
+                    // env b of the call is global env (env_index_base + b) of stream `seed0`: shards and single-env
+                    // calls draw the same instances, and different seeds share none
+                    const uint64_t h = instance_hash(seed0, (uint64_t)(env_index_base + b), 0, (uint32_t)attempt);
                     ok = generate_one(height, width, num_agents, thr, h, nullptr, obstacles + b * cells, true,
                                       agent_xy + (size_t)b * num_agents * 2, target_xy + (size_t)b * num_agents * 2, g);
                 }
@@ -740,8 +766,8 @@ int pgx_generate(int32_t batch, int32_t height, int32_t width, int32_t num_agent
 }
 
 int pgx_place_agents(int32_t batch, int32_t height, int32_t width, int32_t num_agents, uint64_t seed0,
-                     int32_t max_retries, int32_t nthreads, const uint8_t* obstacles, int32_t shared_map,
-                     int32_t* agent_xy, int32_t* target_xy) {
+                     int64_t env_index_base, int32_t max_retries, int32_t nthreads, const uint8_t* obstacles,
+                     int32_t shared_map, int32_t* agent_xy, int32_t* target_xy) {
     if (batch < 1 || height < 1 || width < 1 || num_agents < 1 || !obstacles || !agent_xy || !target_xy)
         return fail(PGX_E_INVALID, "pgx_place_agents: bad argument");
     if (max_retries < 1) max_retries = 10;
@@ -757,7 +783,7 @@ int pgx_place_agents(int32_t batch, int32_t height, int32_t width, int32_t num_a
                 bool ok = false;
                 const uint8_t* m = obstacles + (shared_map ? 0 : b * cells);
                 for (int attempt = 0; attempt < max_retries && !ok; ++attempt) {
-                    const uint64_t h = instance_hash(0, seed0 + (uint64_t)b, 0, (uint32_t)attempt);
+                    const uint64_t h = instance_hash(seed0, (uint64_t)(env_index_base + b), 0, (uint32_t)attempt);
                     ok = generate_one(height, width, num_agents, 0u, h, m, nullptr, attempt == 0 || !shared_map,
                                       agent_xy + (size_t)b * num_agents * 2, target_xy + (size_t)b * num_agents * 2, g);
                 }

@@ -61,6 +61,9 @@ struct StepParams {
     int32_t epw;       // environments per wave (single-wave blocks, num_agents <= 64)
     int32_t obs_u8;    // 1: `obs` is uint8 (one byte per cell) instead of float32
     int32_t stagger;   // cohort stagger of the single-wave kernel (StepGeometry::stagger)
+    int32_t soft_rule;    // PGX_SOFT_*  (docs/SPEC.md Q1)
+    int32_t coop_reward;  // PGX_COOP_REWARD_* (Q4)
+    int32_t bad_action;   // PGX_BAD_ACTION_* (Q7)
     uint32_t flags;    // tuning switches (PGX_FLAGS env var at pgx_create): bit0 = nontemporal obs stores
     uint64_t seed;
     int64_t env_index_base;
@@ -81,6 +84,7 @@ struct StepParams {
     int4* macc;                  // [B]
     float* metrics_out;          // [B][6] ISR, CSR, ep_length, SoC, makespan, avg_throughput (caller-owned, may be null)
     uint8_t* episode_done;       // [B]    1 when the env's episode finished in this step            (may be null)
+    uint32_t* bad_count;         // [1]    out-of-range actions of active agents (bad_action = FLAG)
     // I/O (caller-owned device buffers)
     const void* actions;
     float* obs;
@@ -121,7 +125,8 @@ struct ResetParams {
     int32_t given_state;   // map already installed (pgx_reset_from_state): components + tables only
     int32_t max_retries;
     uint32_t thr;          // obstacle <=> 24 hash bits < thr
-    uint64_t key_base;     // seed + env_index_base: env i draws instance key_base + i
+    uint64_t gen_seed;     // env i of the shard draws instance (gen_seed, env_index_base + i)
+    int64_t env_index_base;
     const uint8_t* shared_map;  // [H*W] given map for every env, or null
     uint8_t* todo;              // [B] in: envs to build; cleared on success
     const uint32_t* epoch;      // [B] generation counters

@@ -140,6 +140,17 @@ __device__ __forceinline__ void lds_sync() {
     }
 }
 
+
+// 16-byte observation store.  policy 0: plain (line stays in the XCD's L2), 1: nontemporal, 2: sc1 (write-through, the
+// line is dropped from L2 -- the observation stream then does not evict the small per-step state from the L2s).
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_obs16(f32x4_t* ptr, f32x4_t v, uint32_t policy) {
+    if (policy == 0u) *ptr = v;
+    else if (policy == 1u) __builtin_nontemporal_store(v, ptr);
+    else if (policy == 2u) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(ptr), "v"(v) : "memory");
+}
+
 // uint8 observation stream (obs_dtype = PGX_OBS_U8; NOT the drop-in dtype -- a 4x lighter mode for callers that
 // cast on their side): the workgroup's n cells as one byte each, 16 per lane per store.  `row_bits(row)` returns
 // the W-bit mask of flat window row `row` (rows past the end read as 0).  16 consecutive cells starting inside row
@@ -307,7 +318,10 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
     // ---- phase 2: state update ---------------------------------------------------------------------
     {
         const uint32_t* obm = s_obst + env_l * bmw;
-        if (act < 0 || act > 4) act = 0;
+        if (act < 0 || act > 4) {  // docs/SPEC.md Q7: a noop either way; FLAG also counts it for the host's IndexError
+            if (p.bad_action != 0 && active && p.mode == MODE_STEP) atomicAdd(p.bad_count, 1u);
+            act = 0;
+        }
         uint32_t cur = to_c22(pos);                     // 22-bit key of the own cell
         uint32_t vis = active ? cur : NOCELL_A;         // ... as seen by others (hidden agents stand nowhere)
 
@@ -360,8 +374,9 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
                     stay = !mover || blocked || o > i || c1 > o;
                 } else {
                     // SURVEY A5 'soft' (net effect of the dict/recursion algorithm): the lowest-index
-                    // claimant of a cell is the only candidate; edge swaps stay.
-                    stay = !mover || blocked || lower;
+                    // claimant of a cell is the only candidate; edge swaps stay.  docs/SPEC.md Q1 alternative
+                    // (PGX_SOFT_ALL_STAY): any other claimant blocks.
+                    stay = !mover || blocked || (p.soft_rule != 0 ? acc.cany < 1024u : lower);
                     uint32_t want_of_o;
                     if constexpr (MW) {
                         want_of_o = nxt >= 0 ? (s_want[nxt] >> 10) : NOCELL_B;
@@ -430,7 +445,7 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
             }
             const bool coop = p.on_target == ON_TARGET_NOTHING;
             const bool fin = p.on_target == ON_TARGET_FINISH;
-            const float rew = (coop ? solved : arrived) ? 1.0f : 0.0f;
+            const float rew = ((coop && p.coop_reward == 0) ? solved : arrived) ? 1.0f : 0.0f;  // Q4
             const uint8_t term = (coop ? solved : (fin && on_goal)) ? 1 : 0;
             const bool all_term = coop ? solved : (fin && all_on_goal);
             if (fin && on_goal) {  // hide_agent
@@ -604,6 +619,7 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
         if (dbg && !dbg2 && tid == 0) p.dbg[(size_t)blk * 4 + 2] = wall_clock64();
         typedef float f32x4 __attribute__((ext_vector_type(4)));
         f32x4* out4 = reinterpret_cast<f32x4*>(out + head);
+        const uint32_t spol = (p.flags & 1u) | ((p.flags >> 3) & 2u) | ((p.flags & 32u) ? 3u : 0u);
         const uint32_t* rows32 = smem;
         // flat float offset e0 = head + 4q advances by 4*NT per iteration: keep (row, col) incrementally
         int e0 = head + (tid << 2);
@@ -619,8 +635,7 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
             v.y = (float)((b >> 1) & 1u);
             v.z = (float)((b >> 2) & 1u);
             v.w = (float)((b >> 3) & 1u);
-            if (p.flags & 1u) __builtin_nontemporal_store(v, &out4[q]);
-            else out4[q] = v;
+            store_obs16(reinterpret_cast<f32x4_t*>(&out4[q]), v, spol);
             col += dcol;
             row += drow;
             if (col >= W) {

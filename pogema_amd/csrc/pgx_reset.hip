@@ -32,8 +32,9 @@ __device__ __forceinline__ uint64_t sm64(uint64_t z) {
     return z ^ (z >> 31);
 }
 
-__device__ __forceinline__ uint64_t instance_hash(uint64_t key, uint32_t epoch, uint32_t attempt) {
-    return sm64(sm64(sm64(0ull) ^ key) ^ (((uint64_t)epoch << 32) | attempt));
+// seed and global env index are separate key components: adjacent seeds share no instance
+__device__ __forceinline__ uint64_t instance_hash(uint64_t seed, uint64_t env, uint32_t epoch, uint32_t attempt) {
+    return sm64(sm64(sm64(seed) ^ env) ^ (((uint64_t)epoch << 32) | attempt));
 }
 
 constexpr uint32_t NONE = 0xFFFFFFFFu;
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(256) void reset_env_kernel(const ResetParams p) {
         const uint32_t epoch = p.epoch[env];
         bool ok = false;
         for (int attempt = 0; attempt < p.max_retries && !ok; ++attempt) {
-            const uint64_t h = instance_hash(p.key_base + (uint64_t)env, epoch, (uint32_t)attempt);
+            const uint64_t h = instance_hash(p.gen_seed, (uint64_t)(p.env_index_base + env), epoch, (uint32_t)attempt);
             const bool redraw = !p.shared_map || attempt == 0;
             for (int c = tid; c < cells; c += 256) {
                 if (redraw)

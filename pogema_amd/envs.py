@@ -44,9 +44,9 @@ except Exception:  # pragma: no cover - exercised only where gymnasium is missin
 
 
 class Pogema:
-    def __init__(self, grid_config: Optional[GridConfig] = None, device="cuda:0", auto_reset=None):
+    def __init__(self, grid_config: Optional[GridConfig] = None, device="cuda:0", auto_reset=None, semantics=None):
         self.grid_config = grid_config if grid_config is not None else GridConfig(num_agents=2)
-        self._vec = VecPogema(self.grid_config, batch=1, device=device, auto_reset=auto_reset)
+        self._vec = VecPogema(self.grid_config, batch=1, device=device, auto_reset=auto_reset, semantics=semantics)
         full = 2 * self.grid_config.obs_radius + 1
         self.observation_space = _Box(0.0, 1.0, shape=(3, full, full), dtype=np.float32)
         self.action_space = _Discrete(len(self.grid_config.MOVES))
@@ -145,6 +145,10 @@ class Pogema:
                                      p["truncated"], p["is_active"], vec._stream()))
         io["host"].copy_(io["dev"], non_blocking=True)
         torch.cuda.current_stream(vec.device).synchronize()
+        if vec.semantics.bad_action == "flag":  # the reference's IndexError on MOVES[action]
+            bad = int(vec._lib.pgx_bad_action_count(vec._handle, vec._stream()))
+            if bad:
+                raise IndexError(f"{bad} action(s) of active agents were outside 0..{len(self.grid_config.MOVES) - 1}")
         v = io["views"]
         obs = v["obs"].copy()
         info_list = [{"is_active": bool(a)} for a in v["is_active"]]
@@ -291,11 +295,13 @@ class PogemaSingleAgent:
         self._env.close()
 
 
-def pogema_v0(grid_config: Optional[GridConfig] = None, device="cuda:0"):
-    """Factory with the reference's name: dispatches on `GridConfig.integration`."""
+def pogema_v0(grid_config: Optional[GridConfig] = None, device="cuda:0", semantics=None):
+    """Factory with the reference's name: dispatches on `GridConfig.integration`.  `semantics`
+    (pogema_amd.Semantics) selects the variants of the low-confidence recollections; default: PGX_SEMANTICS or the
+    recalled behaviour."""
     gc = grid_config if grid_config is not None else GridConfig(num_agents=2)
     if gc.integration is None:
-        return Pogema(gc, device=device)
+        return Pogema(gc, device=device, semantics=semantics)
     if gc.integration == "gymnasium":
         return PogemaSingleAgent(gc, device=device)
     if gc.integration == "PettingZoo":

@@ -26,9 +26,9 @@ def _sm64(z: np.ndarray) -> np.ndarray:
         return z ^ (z >> np.uint64(31))
 
 
-def _instance_hash(key: int, epoch: int = 0, attempt: int = 0) -> np.uint64:
-    h = _sm64(np.array([0], np.uint64))
-    h = _sm64(h ^ np.uint64(key & 0xFFFFFFFFFFFFFFFF))
+def _instance_hash(seed: int, env: int, epoch: int = 0, attempt: int = 0) -> np.uint64:
+    h = _sm64(np.array([seed & 0xFFFFFFFFFFFFFFFF], np.uint64))
+    h = _sm64(h ^ np.uint64(env & 0xFFFFFFFFFFFFFFFF))
     return _sm64(h ^ np.uint64(((epoch & 0xFFFFFFFF) << 32) | (attempt & 0xFFFFFFFF)))[0]
 
 
@@ -52,8 +52,9 @@ def _first_distinct(h: np.uint64, tag: int, n: int, count: int) -> np.ndarray:
     return np.asarray(chosen, np.int64)
 
 
-def place_from_possible(batch: int, seed0: int, possible_agents_xy, possible_targets_xy, num_agents: int):
-    """agents_xy, targets_xy int32 [batch, A, 2]; env b draws from instance (seed0 + b)."""
+def place_from_possible(batch: int, seed0: int, possible_agents_xy, possible_targets_xy, num_agents: int,
+                        env_index_base: int = 0):
+    """agents_xy, targets_xy int32 [batch, A, 2]; env b draws from instance (seed0, env_index_base + b)."""
     pa = np.asarray(possible_agents_xy, np.int32).reshape(-1, 2)
     pt = np.asarray(possible_targets_xy, np.int32).reshape(-1, 2)
     if len(pa) < num_agents or len(pt) < num_agents:
@@ -62,7 +63,7 @@ def place_from_possible(batch: int, seed0: int, possible_agents_xy, possible_tar
     agents = np.empty((batch, num_agents, 2), np.int32)
     targets = np.empty((batch, num_agents, 2), np.int32)
     for b in range(batch):
-        h = _instance_hash(seed0 + b)
+        h = _instance_hash(seed0, env_index_base + b)
         agents[b] = pa[_first_distinct(h, TAG_POSSIBLE_AGENTS, len(pa), num_agents)]
         targets[b] = pt[_first_distinct(h, TAG_POSSIBLE_TARGETS, len(pt), num_agents)]
     return agents, targets

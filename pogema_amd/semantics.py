@@ -1,0 +1,60 @@
+"""Switches for the semantics of the reference that the builder recalls with LOW confidence.
+
+The reference source is not mounted (/root/reference/README.md:3,5 -- "code is hosted elsewhere"), so three details
+of upstream `pogema/envs.py` are recollections that the real package may contradict (docs/SPEC.md open questions
+Q1, Q4, Q7).  Each is a configuration switch -- implemented in the step kernel, in both oracles and in the parity
+matrix -- so that pinning against the real package is a flip here, not a kernel edit:
+
+    soft_vertex   'lowest_index' (default): collision_system='soft', several movers claim one free or vacated cell:
+                                 the lowest agent index moves, the others stay (literal `used_cells[cell].remove(i)`
+                                 + reverse-index loop + recursive `_revert_action`, as recalled);
+                  'all_stay'   : every claimant of a contested cell stays (the textbook MAPF vertex-conflict rule,
+                                 SURVEY.md A5's one-line "net semantics").
+    coop_reward   'all_solved' (default): on_target='nothing' pays 1.0 to every agent iff ALL agents stand on their
+                                 goals (`is_task_solved`);
+                  'per_agent'  : 1.0 to each agent standing on its own goal in this step.
+    bad_action    'noop' (default): an action outside 0..4 does nothing;
+                  'flag'       : the device still treats it as a noop but counts it, and `step()` raises the
+                                 reference's IndexError (`MOVES[action]`) -- costs one host sync per step.
+
+`PGX_SEMANTICS="soft_vertex=all_stay,coop_reward=per_agent"` overrides the defaults process-wide (one-step pinning
+of a whole test run against fixtures from the real package).
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+
+SOFT_VERTEX = ("lowest_index", "all_stay")
+COOP_REWARD = ("all_solved", "per_agent")
+BAD_ACTION = ("noop", "flag")
+
+
+@dataclass(frozen=True)
+class Semantics:
+    soft_vertex: str = "lowest_index"
+    coop_reward: str = "all_solved"
+    bad_action: str = "noop"
+
+    def __post_init__(self):
+        for name, allowed in (("soft_vertex", SOFT_VERTEX), ("coop_reward", COOP_REWARD), ("bad_action", BAD_ACTION)):
+            if getattr(self, name) not in allowed:
+                raise ValueError(f"Semantics.{name} must be one of {allowed}, got {getattr(self, name)!r}")
+
+    @classmethod
+    def from_env(cls) -> "Semantics":
+        """The process-wide default: built-in defaults overridden by PGX_SEMANTICS."""
+        spec = os.environ.get("PGX_SEMANTICS", "").strip()
+        kw = {}
+        for item in filter(None, (s.strip() for s in spec.split(","))):
+            if "=" not in item:
+                raise ValueError(f"PGX_SEMANTICS entry {item!r} is not key=value")
+            k, v = item.split("=", 1)
+            if k not in ("soft_vertex", "coop_reward", "bad_action"):
+                raise ValueError(f"PGX_SEMANTICS: unknown switch {k!r}")
+            kw[k] = v
+        return cls(**kw)
+
+    def oracle_kwargs(self) -> dict:
+        """The same switches under the oracles' parameter names (tests only)."""
+        return {"soft_vertex_rule": self.soft_vertex, "coop_reward": self.coop_reward, "bad_action": self.bad_action}

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import warnings
 from typing import Optional
 
 import numpy as np
@@ -17,6 +18,7 @@ import torch
 
 from . import _lib
 from .grid_config import GridConfig
+from .semantics import Semantics
 
 
 def _as_device_index(device) -> int:
@@ -36,14 +38,21 @@ class VecPogema:
                 'metrics': float32 [batch, 6] (ISR, CSR, ep_length, SoC, makespan, avg_throughput; a row is
                 refreshed on the step where its env's episode ends -- mask with 'episode_done')}
 
-    Throughput: pass `reuse_buffers=True` -- the outputs then live in two alternating, engine-probed buffers (an
-    observation tensor is valid until the step after next) instead of fresh allocations whose placement in HBM is
-    arbitrary (the same kernel runs 140..153 us per step depending on where its output buffer lives).
+    Throughput: pass `reuse_buffers=True` -- the outputs then live in two alternating, engine-probed buffers instead
+    of fresh allocations whose placement in HBM is arbitrary (the same kernel runs 140..153 us per step depending on
+    where its output buffer lives).  ALIASING: with `reuse_buffers=True` every tensor returned by step t (obs, rewards,
+    terminated, truncated, infos['is_active']) is overwritten by step t+2 -- consume or copy it before then, or hand
+    step() your own buffers with `out=`.
+
+    `semantics`: switches for the three low-confidence recollections of the reference (pogema_amd/semantics.py).
+    Seeds: `reset(seed)` selects the instances (maps, starts, targets); the lifelong target stream and the
+    `empty_outside=False` obstacles are keyed by `GridConfig.seed` (fixed at construction) and the global env index.
     """
 
     def __init__(self, grid_config: Optional[GridConfig] = None, batch: int = 1, device="cuda:0",
                  env_index_base: int = 0, auto_reset: Optional[bool] = None, reuse_buffers: bool = False,
-                 obs_dtype=torch.float32):
+                 obs_dtype=torch.float32, semantics: Optional[Semantics] = None,
+                 placement_probe: Optional[bool] = None):
         self.grid_config = grid_config if grid_config is not None else GridConfig(num_agents=2)
         gc = self.grid_config
         self.observation_type = gc.observation_type  # 'default' tensor, or 'POMAPF' / 'MAPF' dict views
@@ -73,6 +82,9 @@ class VecPogema:
             raise NotImplementedError("auto_reset='regenerate' needs random instances and observation_type='default'")
         self.auto_reset = bool(auto_reset)
         self.reuse_buffers = bool(reuse_buffers)
+        self.semantics = semantics if semantics is not None else Semantics.from_env()
+        # placement probe of the double-buffered observation tensors (reuse_buffers=True); PGX_PLACEMENT=0 disables
+        self.placement_probe = (os.environ.get("PGX_PLACEMENT") != "0") if placement_probe is None else bool(placement_probe)
         # float32 is the reference's observation dtype (gymnasium Box float32) and the default; torch.uint8 writes
         # the same 0/1 planes one byte per cell (4x fewer HBM bytes per step) for callers that cast on their side
         if obs_dtype not in _lib.OBS_DTYPES:
@@ -85,7 +97,9 @@ class VecPogema:
             on_target=_lib.ON_TARGET[gc.on_target], max_episode_steps=int(gc.max_episode_steps),
             auto_reset=int(self.auto_reset), obs_dtype=_lib.OBS_DTYPES[self.obs_dtype], seed=int(gc.seed or 0),
             env_index_base=self.env_index_base, random_outside=0 if gc.empty_outside else 1,
-            outside_density=float(gc.density))
+            outside_density=float(gc.density), soft_vertex_rule=_lib.SOFT_VERTEX_RULES[self.semantics.soft_vertex],
+            coop_reward=_lib.COOP_REWARDS[self.semantics.coop_reward],
+            bad_action=_lib.BAD_ACTIONS[self.semantics.bad_action])
         self._handle = C.c_void_p()
         _lib.check(self._lib.pgx_create(C.byref(cfg), self.device_index, C.byref(self._handle)))
         self._bufs = None
@@ -130,7 +144,7 @@ class VecPogema:
         (obstacles u8 [B,H,W], agents_xy i32 [B,A,2], targets_xy i32 [B,A,2])."""
         gc = self.grid_config
         B, H, Wd, A = self.batch, self.height, self.width, self.num_agents
-        seed0 = (self._resolve_seed(seed) + self.env_index_base) & 0xFFFFFFFFFFFFFFFF
+        seed0 = self._resolve_seed(seed)
         agents = np.empty((B, A, 2), dtype=np.int32)
         targets = np.empty((B, A, 2), dtype=np.int32)
         if gc.map is not None:
@@ -141,34 +155,45 @@ class VecPogema:
                 targets[:] = np.asarray(gc.targets_xy, dtype=np.int32)[None]
             elif self._possible:
                 from .generator_host import place_from_possible
-                agents, targets = place_from_possible(B, seed0, gc.possible_agents_xy, gc.possible_targets_xy, A)
+                agents, targets = place_from_possible(B, seed0, gc.possible_agents_xy, gc.possible_targets_xy, A,
+                                                      env_index_base=self.env_index_base)
             else:
-                _lib.check(self._lib.pgx_place_agents(B, H, Wd, A, seed0, 10, 0, one.ctypes.data, 1,
+                _lib.check(self._lib.pgx_place_agents(B, H, Wd, A, seed0, self.env_index_base, 10, 0, one.ctypes.data, 1,
                                                       agents.ctypes.data, targets.ctypes.data))
         else:
             obstacles = np.empty((B, H, Wd), dtype=np.uint8)
             if gc.agents_xy is not None:
                 raise NotImplementedError("agents_xy/targets_xy need an explicit `map`")
-            _lib.check(self._lib.pgx_generate(B, H, Wd, A, float(gc.density), seed0, 10, 0,
+            _lib.check(self._lib.pgx_generate(B, H, Wd, A, float(gc.density), seed0, self.env_index_base, 10, 0,
                                               obstacles.ctypes.data, agents.ctypes.data, targets.ctypes.data))
         return obstacles, agents, targets
 
     @staticmethod
-    def _validate_state(obstacles, agents, targets):
+    def _validate_state(obstacles, agents, targets, on_obstacle: str = "raise"):
+        """Starts/targets must lie on free cells and no two agents may share a start cell.  on_obstacle='raise'
+        (KeyError, what the oracle's Grid does) or 'free' (the cell is freed with a warning -- upstream `Grid.__init__`
+        as recalled: "There is an obstacle on a start point ..., replacing with free cell"); `obstacles` is edited in
+        place in that case.  Two agents on one start cell always raise."""
         B, A = agents.shape[:2]
         bi = np.arange(B)[:, None]
-        if (obstacles[bi, agents[..., 0], agents[..., 1]] != 0).any():
-            raise KeyError("an agent start lies on an obstacle")
-        if (obstacles[bi, targets[..., 0], targets[..., 1]] != 0).any():
-            raise KeyError("a target lies on an obstacle")
+        for what, pts in (("an agent start", agents), ("a target", targets)):
+            hit = obstacles[bi, pts[..., 0], pts[..., 1]] != 0
+            if hit.any():
+                if on_obstacle != "free":
+                    raise KeyError(f"{what} lies on an obstacle")
+                b, a = np.argwhere(hit)[0]
+                warnings.warn(f"{what} lies on an obstacle (first: env {b}, agent {a}, cell "
+                              f"({pts[b, a, 0]}, {pts[b, a, 1]})); replacing with a free cell", stacklevel=3)
+                obstacles[bi, pts[..., 0], pts[..., 1]] = 0
         w = obstacles.shape[2]
         flat = np.sort(agents[..., 0].astype(np.int64) * w + agents[..., 1], axis=1)
         if A > 1 and (flat[:, 1:] == flat[:, :-1]).any():
             raise KeyError("two agents share a start cell")
 
-    def reset_from_state(self, obstacles, agents_xy, targets_xy, validate: bool = True):
+    def reset_from_state(self, obstacles, agents_xy, targets_xy, validate: bool = True, on_obstacle: str = "raise"):
         """Install explicit initial states (numpy or torch; broadcast over the batch when 2-D/3-D
-        inputs lack the batch axis) and return the first observation."""
+        inputs lack the batch axis) and return the first observation.  `validate` (default on, O(B*A) numpy work):
+        see `_validate_state`."""
         B, H, Wd, A = self.batch, self.height, self.width, self.num_agents
 
         def to_np(v, dtype):
@@ -195,7 +220,7 @@ class VecPogema:
         agents_xy = np.ascontiguousarray(agents_xy)
         targets_xy = np.ascontiguousarray(targets_xy)
         if validate:
-            self._validate_state(obstacles, agents_xy, targets_xy)
+            self._validate_state(obstacles, agents_xy, targets_xy, on_obstacle)
         d_obst = torch.from_numpy(obstacles).to(self.device)
         d_agents = torch.from_numpy(agents_xy).to(self.device)
         d_targets = torch.from_numpy(targets_xy).to(self.device)
@@ -232,15 +257,17 @@ class VecPogema:
         gc = self.grid_config
         if gc.map is not None and (gc.agents_xy is not None or self._possible):
             obstacles, agents, targets = self.generate(seed)
-            obs = self.reset_from_state(obstacles, agents, targets, validate=self._possible)
+            # user-supplied cells: always validated; an obstacle under a start/target is freed with a warning
+            obs = self.reset_from_state(obstacles, agents, targets, validate=True, on_obstacle="free")
         else:
             if gc.agents_xy is not None:
                 raise NotImplementedError("agents_xy/targets_xy need an explicit `map`")
             shared = self._shared_map_tensor()
-            _lib.check(self._lib.pgx_reset_random(self._handle, float(gc.density), self._resolve_seed(seed),
+            resolved = self._resolve_seed(seed)  # once: with seed=None every call draws fresh OS entropy
+            _lib.check(self._lib.pgx_reset_random(self._handle, float(gc.density), resolved,
                                                   shared.data_ptr() if shared is not None else None, None, 10,
                                                   self._stream()))
-            self._reset_seed = self._resolve_seed(seed)
+            self._reset_seed = resolved
             self._refresh_initial()
             obs = self._wrap_obs(self.observe())
         infos = {"is_active": torch.ones((self.batch, self.num_agents), dtype=torch.bool, device=self.device)}
@@ -294,11 +321,11 @@ class VecPogema:
     def _pick_obs_buffers(self):
         obs_bytes = int(np.prod(self.obs_shape)) * (4 if self.obs_dtype == torch.float32 else 1)
         batch_n = self.PLACEMENT_CANDIDATES if obs_bytes >= self.PLACEMENT_MIN_BYTES else 2
-        if os.environ.get("PGX_PLACEMENT") == "0":  # diagnostic: take the first two buffers as they come
-            batch_n = 2
         free, _ = torch.cuda.mem_get_info(self.device)
         budget = max(2, int(free * 0.25) // max(obs_bytes, 1))   # candidates alive at once
         new = lambda k: [torch.empty(self.obs_shape, dtype=self.obs_dtype, device=self.device) for _ in range(k)]
+        if not self.placement_probe:
+            batch_n = 2
         if batch_n == 2 or not self._has_state():
             return new(2)
         timed = []
@@ -350,11 +377,36 @@ class VecPogema:
 
     _ACTION_CODE = {torch.int8: 0, torch.int32: 1, torch.int64: 2}
 
-    def step(self, actions, compute_obs: bool = True):
+    def _check_out(self, out):
+        """`out=(obs, rewards, terminated, truncated, is_active)`: caller-owned output tensors on this device."""
+        if len(out) != 5:
+            raise ValueError("out must be (obs, rewards, terminated, truncated, is_active)")
+        B, A = self.batch, self.num_agents
+        want = ((self.obs_shape, self.obs_dtype), ((B, A), torch.float32), ((B, A), torch.bool), ((B, A), torch.bool),
+                ((B, A), torch.bool))
+        for name, t, (shape, dtype) in zip(("obs", "rewards", "terminated", "truncated", "is_active"), out, want):
+            if t is None and name == "obs":
+                continue
+            ok_dtype = t.dtype == dtype or (dtype == torch.bool and t.dtype == torch.uint8)
+            if tuple(t.shape) != tuple(shape) or not ok_dtype or not t.is_contiguous() or t.device != self.device:
+                raise ValueError(f"out[{name}] must be a contiguous {dtype} tensor of shape {tuple(shape)} on {self.device}")
+        return out
+
+    def step(self, actions, compute_obs: bool = True, out=None):
         """One step of every environment.  `actions`: int tensor [batch, agents] with values 0..4
-        (noop, up, down, left, right).  Returns (obs, rewards, terminated, truncated, infos)."""
+        (noop, up, down, left, right).  Returns (obs, rewards, terminated, truncated, infos).
+
+        Output buffers: fresh tensors per call by default; with `reuse_buffers=True` two alternating sets, so whatever
+        step t returned is OVERWRITTEN BY STEP t+2 (consume or copy it before); with
+        `out=(obs, rewards, terminated, truncated, is_active)` the caller's own tensors are written (bool or uint8
+        flags; `obs` may be None together with compute_obs=False) and returned."""
         actions = self._prepare_actions(actions)
-        obs, rewards, terminated, truncated, is_active = self._outputs()
+        if out is not None:
+            obs, rewards, terminated, truncated, is_active = self._check_out(out)
+            if compute_obs and obs is None:
+                raise ValueError("out[obs] is None but compute_obs=True")
+        else:
+            obs, rewards, terminated, truncated, is_active = self._outputs()
         _lib.check(self._lib.pgx_step(
             self._handle, actions.data_ptr(), self._ACTION_CODE[actions.dtype],
             obs.data_ptr() if compute_obs else None, rewards.data_ptr(), terminated.data_ptr(),
@@ -368,6 +420,12 @@ class VecPogema:
                 self._handle, self.episode_done.data_ptr(), float(self.grid_config.density), self._reset_seed,
                 self._shared.data_ptr() if self._shared is not None else None, 3,
                 obs.data_ptr() if compute_obs else None, self._stream()))
+        if self.semantics.bad_action == "flag":  # the reference's IndexError on MOVES[action]; one host sync per step
+            bad = int(self._lib.pgx_bad_action_count(self._handle, self._stream()))
+            if bad < 0:
+                _lib.check(bad)
+            if bad:
+                raise IndexError(f"{bad} action(s) of active agents were outside 0..{len(self.grid_config.MOVES) - 1}")
         infos = {"is_active": is_active, "episode_done": self.episode_done, "metrics": self.metrics}
         return (self._wrap_obs(obs) if compute_obs else None), rewards, terminated, truncated, infos
 

@@ -152,7 +152,7 @@ def test_list_api_state_accessors():
     gc = GridConfig(size=10, num_agents=4, obs_radius=2, density=0.2, seed=13, collision_system="priority")
     env = pogema_v0(gc)
     env.reset(seed=13)
-    ro, ra, rt = G.generate_instance(0, 13, 10, 10, 4, 0.2)
+    ro, ra, rt = G.generate_instance(13, 0, 10, 10, 4, 0.2)
     assert np.array_equal(env.get_obstacles(), ro)
     assert env.get_agents_xy() == [tuple(p) for p in ra.tolist()] and env.get_targets_xy() == [tuple(p) for p in rt.tolist()]
     ref = PogemaOracle(ro, ra, rt, obs_radius=2, collision_system="priority", max_episode_steps=64)
@@ -205,7 +205,7 @@ def test_possible_positions_reset():
     env.reset(seed=8)
     st = env.get_state()
     for b in range(5):
-        ra, rt = G.place_from_possible(0, 8 + 2 + b, gc.possible_agents_xy, gc.possible_targets_xy, 3)
+        ra, rt = G.place_from_possible(8, 2 + b, gc.possible_agents_xy, gc.possible_targets_xy, 3)
         assert np.array_equal(st["agents_xy"][b].cpu().numpy(), ra) and np.array_equal(st["targets_xy"][b].cpu().numpy(), rt)
     env.close()
 

@@ -25,7 +25,7 @@ def _fnv(h, arr):
     return h
 
 
-def _generate(B, S, A, density, key_base):
+def _generate(B, S, A, density, seed, base):
     from oracle.c_oracle import load
     lib = load()
     lib.po_generate.argtypes = [C.c_int32] * 4 + [C.c_float, C.c_uint64, C.c_int64, C.c_void_p, C.c_int32, C.c_int32,
@@ -34,7 +34,7 @@ def _generate(B, S, A, density, key_base):
     o = np.empty((B, S, S), np.uint8)
     a = np.empty((B, A, 2), np.int32)
     t = np.empty((B, A, 2), np.int32)
-    assert lib.po_generate(B, S, S, A, density, 0, key_base, None, 10, 0, o.ctypes.data, a.ctypes.data, t.ctypes.data) == 0
+    assert lib.po_generate(B, S, S, A, density, seed, base, None, 10, 0, o.ctypes.data, a.ctypes.data, t.ctypes.data) == 0
     return o, a, t
 
 
@@ -48,7 +48,7 @@ def test_native_program_matches_oracle(case):
     assert out.returncode == 0, out.stderr
     got = dict(kv.split("=") for kv in out.stdout.split())
     base = 5  # cfg.env_index_base in the program
-    o, a, t = _generate(B, S, A, 0.3, seed + base)
+    o, a, t = _generate(B, S, A, 0.3, seed, base)
     gi = np.arange(B * A)
     actions = np.stack([((tt * 7 + (gi // A) * 3 + (gi % A) * 5 + ((tt + gi) >> 2)) % 5).reshape(B, A)
                         for tt in range(T)]).astype(np.int64)

@@ -13,7 +13,7 @@ NOWHERE = ("nowhere",)
 NOTHING = ("nothing",)
 
 
-def closed_form_moves(obst_padded, cur, active, actions, collision):
+def closed_form_moves(obst_padded, cur, active, actions, collision, soft_vertex_rule="lowest_index"):
     """New padded cells per agent, following the kernel's rules (one 'lane' per agent)."""
     n = len(cur)
     mover = [active[i] and actions[i] != 0 for i in range(n)]
@@ -38,7 +38,7 @@ def closed_form_moves(obst_padded, cur, active, actions, collision):
         if collision == "priority":
             stay[i] = (not mover[i]) or blocked[i] or o > i or c1 > o
         else:
-            stay[i] = (not mover[i]) or blocked[i] or bool(lower)
+            stay[i] = (not mover[i]) or blocked[i] or bool(lower if soft_vertex_rule == "lowest_index" else others[i])
             if nxt[i] >= 0 and want[nxt[i]] == cur[i]:
                 stay[i] = True  # edge swap
     if collision != "block_both":
@@ -76,19 +76,21 @@ def scenarios(draw):
     return obstacles, starts, targets, actions
 
 
-@pytest.mark.parametrize("collision", ["priority", "block_both", "soft"])
+@pytest.mark.parametrize("collision", ["priority", "block_both", "soft", "soft/all_stay"])
 @pytest.mark.parametrize("on_target", ["finish", "nothing"])
 @settings(max_examples=1500, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large])
 @given(sc=scenarios())
 def test_closed_form_equals_literal_algorithm(collision, on_target, sc):
     obstacles, starts, targets, actions = sc
+    collision, _, rule = collision.partition("/")  # 'soft/all_stay': the docs/SPEC.md Q1 alternative
+    rule = rule or "lowest_index"
     env = PogemaOracle(obstacles, starts, targets, obs_radius=1, collision_system=collision, on_target=on_target,
-                       max_episode_steps=1000)
+                       max_episode_steps=1000, soft_vertex_rule=rule)
     g = env.grid
     for acts in actions:
         cur = list(g.positions_xy)
         active = [bool(g.is_active[i]) for i in range(len(cur))]
-        expect = closed_form_moves(g.obstacles, cur, active, acts, collision)
+        expect = closed_form_moves(g.obstacles, cur, active, acts, collision, rule)
         env.step(list(acts))
         assert list(g.positions_xy) == expect, (collision, cur, active, acts)
         # invariants every collision system keeps

@@ -41,7 +41,7 @@ def _instances(c):
     o = np.empty((c["B"], c["H"], c["W"]), np.uint8)
     a = np.empty((c["B"], c["A"], 2), np.int32)
     t = np.empty((c["B"], c["A"], 2), np.int32)
-    st = lib.po_generate(c["B"], c["H"], c["W"], c["A"], c["density"], 0, c["seed"], None, 30, 0, o.ctypes.data,
+    st = lib.po_generate(c["B"], c["H"], c["W"], c["A"], c["density"], c["seed"], 0, None, 30, 0, o.ctypes.data,
                          a.ctypes.data, t.ctypes.data)
     return st, o, a, t
 
@@ -95,7 +95,7 @@ def test_random_device_resets(chunk):
         if shared:
             given = (rng.random((S, S)) < density).astype(np.uint8)
             o = given.copy()
-        st = lib.po_generate(B, S, S, A, density, 0, seed + base, None, 10, int(shared), o.ctypes.data, a.ctypes.data,
+        st = lib.po_generate(B, S, S, A, density, seed, base, None, 10, int(shared), o.ctypes.data, a.ctypes.data,
                              t.ctypes.data)
         if st != 0:
             continue
@@ -114,7 +114,7 @@ def test_random_device_resets(chunk):
             ep = mask.astype(np.uint32)
             o2 = o.copy()
             a2, t2 = a.copy(), t.copy()
-            st = lib.po_generate(B, S, S, A, density, 0, seed + base, ep.ctypes.data, 10, int(shared), o2.ctypes.data,
+            st = lib.po_generate(B, S, S, A, density, seed, base, ep.ctypes.data, 10, int(shared), o2.ctypes.data,
                                  a2.ctypes.data, t2.ctypes.data)
             if st == 0:
                 env.reset_where(torch.from_numpy(mask).cuda())

@@ -35,9 +35,13 @@ def test_density_and_determinism():
         assert np.array_equal(x, y)
     assert not np.array_equal(a[0], c[0])
     assert abs(a[0].mean() - 0.3) < 0.02
-    # env i of seed s equals env 0 of seed s+i (per-env streams: sharding-independent)
-    d = generate_instances(1, 32, 32, 4, 0.3, 5 + 7)
+    # global env i of seed s is the same instance wherever its shard starts (per-env streams: sharding-independent)
+    d = generate_instances(1, 32, 32, 4, 0.3, 5, env_index_base=7)
     assert np.array_equal(a[0][7], d[0][0]) and np.array_equal(a[1][7], d[1][0])
+    # seed and env index are separate key components: adjacent seeds share NO instance (a train/eval split by seed
+    # must not see shifted copies of the same maps)
+    maps_a = {m.tobytes() for m in a[0]}
+    assert not any(m.tobytes() in maps_a for m in c[0])
 
 
 def test_thread_count_independent(engine_lib):
@@ -46,7 +50,7 @@ def test_thread_count_independent(engine_lib):
         o = np.empty((40, 12, 12), np.uint8)
         a = np.empty((40, 6, 2), np.int32)
         t = np.empty((40, 6, 2), np.int32)
-        _lib.check(engine_lib.pgx_generate(40, 12, 12, 6, C.c_float(0.25), 3, 10, nt, o.ctypes.data, a.ctypes.data, t.ctypes.data))
+        _lib.check(engine_lib.pgx_generate(40, 12, 12, 6, C.c_float(0.25), 3, 0, 10, nt, o.ctypes.data, a.ctypes.data, t.ctypes.data))
         outs.append((o, a, t))
     for o, a, t in outs[1:]:
         assert np.array_equal(o, outs[0][0]) and np.array_equal(a, outs[0][1]) and np.array_equal(t, outs[0][2])
@@ -56,9 +60,9 @@ def test_overflow_is_an_error(engine_lib):
     o = np.empty((1, 4, 4), np.uint8)
     a = np.empty((1, 9, 2), np.int32)
     t = np.empty((1, 9, 2), np.int32)
-    status = engine_lib.pgx_generate(1, 4, 4, 9, C.c_float(0.0), 0, 3, 1, o.ctypes.data, a.ctypes.data, t.ctypes.data)
+    status = engine_lib.pgx_generate(1, 4, 4, 9, C.c_float(0.0), 0, 0, 3, 1, o.ctypes.data, a.ctypes.data, t.ctypes.data)
     assert status == -5 and "agents" in engine_lib.pgx_last_error().decode()
-    status = engine_lib.pgx_generate(1, 4, 4, 4, C.c_float(0.9), 0, 3, 1, o.ctypes.data, a.ctypes.data, t.ctypes.data)
+    status = engine_lib.pgx_generate(1, 4, 4, 4, C.c_float(0.9), 0, 0, 3, 1, o.ctypes.data, a.ctypes.data, t.ctypes.data)
     assert status == -5
 
 
@@ -67,7 +71,7 @@ def test_place_on_given_map(engine_lib):
     m[2, :] = 1  # wall splits the map in two components
     a = np.empty((8, 3, 2), np.int32)
     t = np.empty((8, 3, 2), np.int32)
-    _lib.check(engine_lib.pgx_place_agents(8, 5, 7, 3, 42, 10, 2, m.ctypes.data, 1, a.ctypes.data, t.ctypes.data))
+    _lib.check(engine_lib.pgx_place_agents(8, 5, 7, 3, 42, 0, 10, 2, m.ctypes.data, 1, a.ctypes.data, t.ctypes.data))
     assert ((a[..., 0] < 2) == (t[..., 0] < 2)).all(), "pairs stay on their side of the wall"
     assert (m[a[..., 0], a[..., 1]] == 0).all() and (m[t[..., 0], t[..., 1]] == 0).all()
 
@@ -76,7 +80,7 @@ def test_place_on_given_map(engine_lib):
 GEN_CASES = [(6, 8, 8, 2, 0.3, 11), (5, 16, 16, 8, 0.3, 3), (3, 9, 21, 30, 0.1, 77), (2, 32, 32, 16, 0.45, 5)]
 
 
-def _c_generate(B, H, W, A, density, key_base, given_map=None, epochs=None, max_retries=50):
+def _c_generate(B, H, W, A, density, seed, base=0, given_map=None, epochs=None, max_retries=50):
     from oracle.c_oracle import load
     lib = load()
     lib.po_generate.argtypes = [C.c_int32] * 4 + [C.c_float, C.c_uint64, C.c_int64, C.c_void_p, C.c_int32, C.c_int32,
@@ -86,7 +90,7 @@ def _c_generate(B, H, W, A, density, key_base, given_map=None, epochs=None, max_
     a = np.empty((B, A, 2), np.int32)
     t = np.empty((B, A, 2), np.int32)
     ep = None if epochs is None else np.ascontiguousarray(epochs, np.uint32).ctypes.data
-    st = lib.po_generate(B, H, W, A, density, 0, key_base, ep, max_retries, int(given_map is not None), o.ctypes.data,
+    st = lib.po_generate(B, H, W, A, density, seed, base, ep, max_retries, int(given_map is not None), o.ctypes.data,
                          a.ctypes.data, t.ctypes.data)
     return st, o, a, t
 
@@ -96,7 +100,7 @@ def test_host_generator_equals_oracles(case):
     from oracle import generator_oracle as G
     B, H, W, A, density, seed = case
     o, a, t = generate_instances(B, H, W, A, density, seed)
-    ro, ra, rt = G.generate_batch(0, B, H, W, A, density, env_index_base=seed, max_retries=50)
+    ro, ra, rt = G.generate_batch(seed, B, H, W, A, density, env_index_base=0, max_retries=50)
     assert np.array_equal(o, ro) and np.array_equal(a, ra) and np.array_equal(t, rt)
     st, co, ca, ct = _c_generate(B, H, W, A, density, seed)
     assert st == 0 and np.array_equal(o, co) and np.array_equal(a, ca) and np.array_equal(t, ct)
@@ -107,11 +111,11 @@ def test_generator_oracle_epochs_and_given_map():
     m = np.zeros((5, 7), np.uint8)
     m[2, :] = 1
     for epoch in (0, 1, 5):
-        _, pa, pt = G.generate_instance(0, 42, 5, 7, 3, 0.0, epoch=epoch, given_map=m)
+        _, pa, pt = G.generate_instance(42, 0, 5, 7, 3, 0.0, epoch=epoch, given_map=m)
         st, _, ca, ct = _c_generate(1, 5, 7, 3, 0.0, 42, given_map=m, epochs=[epoch])
         assert st == 0 and np.array_equal(pa, ca[0]) and np.array_equal(pt, ct[0])
-    a0 = G.generate_instance(0, 42, 5, 7, 3, 0.0, epoch=0, given_map=m)[1]
-    a1 = G.generate_instance(0, 42, 5, 7, 3, 0.0, epoch=1, given_map=m)[1]
+    a0 = G.generate_instance(42, 0, 5, 7, 3, 0.0, epoch=0, given_map=m)[1]
+    a1 = G.generate_instance(42, 0, 5, 7, 3, 0.0, epoch=1, given_map=m)[1]
     assert not np.array_equal(a0, a1), "a new generation draws a new placement"
     with pytest.raises(OverflowError):
         G.generate_instance(0, 0, 4, 4, 9, 0.0)
@@ -139,7 +143,7 @@ def test_possible_positions_host_equals_oracle():
     pt = [(3, 3), (0, 1), (5, 0), (2, 4)]
     agents, targets = place_from_possible(6, 100, pa, pt, 3)
     for b in range(6):
-        ra, rt = G.place_from_possible(0, 100 + b, pa, pt, 3)
+        ra, rt = G.place_from_possible(100, b, pa, pt, 3)
         assert np.array_equal(agents[b], ra) and np.array_equal(targets[b], rt)
         assert len({tuple(p) for p in agents[b]}) == 3 and len({tuple(p) for p in targets[b]}) == 3
         assert all(tuple(p) in pa for p in agents[b].tolist()) and all(tuple(p) in pt for p in targets[b].tolist())
@@ -167,14 +171,14 @@ def test_host_generator_fuzz_against_oracles():
         a = np.empty((B, A, 2), np.int32)
         t = np.empty((B, A, 2), np.int32)
         lib = _lib.load()
-        st = lib.pgx_generate(B, H, W, A, C.c_float(density), seed, 6, 2, o.ctypes.data, a.ctypes.data, t.ctypes.data)
+        st = lib.pgx_generate(B, H, W, A, C.c_float(density), seed, 0, 6, 2, o.ctypes.data, a.ctypes.data, t.ctypes.data)
         cst, co, ca, ct = _c_generate(B, H, W, A, density, seed, max_retries=6)
         assert (st == 0) == (cst == 0), (H, W, A, density, seed)
         if st != 0:
             continue
         assert np.array_equal(o, co) and np.array_equal(a, ca) and np.array_equal(t, ct), (H, W, A, density, seed)
         if H * W <= 300 and checked_py < 15:
-            ro, ra, rt = G.generate_batch(0, B, H, W, A, density, env_index_base=seed, max_retries=6)
+            ro, ra, rt = G.generate_batch(seed, B, H, W, A, density, env_index_base=0, max_retries=6)
             assert np.array_equal(o, ro) and np.array_equal(a, ra) and np.array_equal(t, rt)
             checked_py += 1
     assert checked_py >= 5

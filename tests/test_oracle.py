@@ -7,7 +7,8 @@ import zlib
 import numpy as np
 import pytest
 
-from util import assert_rollouts_equal, c_oracle_rollout, generate_instances, oracle_rollout, random_actions
+from util import (assert_rollouts_equal, c_oracle_rollout, check_spec_case, generate_instances, oracle_rollout,
+                  random_actions)
 
 COLLISIONS = ("priority", "block_both", "soft")
 ON_TARGET = ("finish", "restart", "nothing")
@@ -38,6 +39,27 @@ def test_c_port_equals_python_oracle(geom, collision, on_target):
         assert_rollouts_equal(ref, got, f"{name}/{collision}/{on_target}/{auto_reset}")
 
 
+@pytest.mark.parametrize("geom", [g for g in GEOMS if g[0] in ("dense", "crowd", "rect")], ids=lambda g: g[0])
+@pytest.mark.parametrize("on_target", ON_TARGET)
+def test_c_port_equals_python_oracle_semantics_variants(geom, on_target):
+    """docs/SPEC.md Q1 / Q4 alternatives (soft 'all_stay', coop 'per_agent'): the two oracles agree there too, and the
+    variants really differ from the defaults on crowded instances."""
+    from pogema_amd.semantics import Semantics
+    name, B, H, Wd, A, r, density, T, max_steps = geom
+    seed = zlib.crc32(f"variants/{name}/{on_target}".encode()) % (2 ** 31)
+    obstacles, agents, targets = generate_instances(B, H, Wd, A, density, seed)
+    actions = random_actions(T, B, A, seed + 1)
+    sem = Semantics(soft_vertex="all_stay", coop_reward="per_agent")
+    kw = dict(obs_radius=r, collision_system="soft", on_target=on_target, max_episode_steps=max_steps, auto_reset=True,
+              seed=77, env_index_base=3)
+    ref = oracle_rollout(obstacles, agents, targets, actions, semantics=sem, **kw)
+    got = c_oracle_rollout(obstacles, agents, targets, actions, semantics=sem, **kw)
+    assert_rollouts_equal(ref, got, f"variants/{name}/{on_target}")
+    base = oracle_rollout(obstacles, agents, targets, actions, **kw)
+    if name in ("dense", "crowd"):
+        assert not np.array_equal(base["agents_xy"], ref["agents_xy"]), "all_stay must differ from lowest_index somewhere"
+
+
 def test_c_port_threads_deterministic():
     B, H, Wd, A, r = 16, 12, 12, 20, 3
     obstacles, agents, targets = generate_instances(B, H, Wd, A, 0.2, 4)
@@ -57,26 +79,7 @@ def _load_spec_vectors():
 @pytest.mark.parametrize("impl", ["python", "c"])
 def test_spec_vectors(case, impl):
     """Hand-derived expectations (SURVEY section 8a SPEC column) -- NOT outputs of the reference."""
-    obstacles = np.array(case["map"], np.uint8)[None]
-    agents = np.array(case["agents_xy"], np.int32)[None]
-    targets = np.array(case["targets_xy"], np.int32)[None]
-    actions = np.array(case["actions"], np.int64)[:, None, :]
-    kw = dict(obs_radius=case["obs_radius"], collision_system=case["collision_system"], on_target=case["on_target"],
-              max_episode_steps=case.get("max_episode_steps", 64), auto_reset=False)
-    run = oracle_rollout if impl == "python" else c_oracle_rollout
-    out = run(obstacles, agents, targets, actions, **kw)
-    exp = case["expect"]
-    assert out["agents_xy"][:, 0].tolist() == exp["agents_xy"], case["why"]
-    if "rewards" in exp:
-        assert out["rewards"][:, 0].tolist() == exp["rewards"]
-    if "terminated" in exp:
-        assert out["terminated"][:, 0].astype(int).tolist() == exp["terminated"]
-    if "truncated" in exp:
-        assert out["truncated"][:, 0].astype(int).tolist() == exp["truncated"]
-    if "is_active" in exp:
-        assert out["is_active"][:, 0].astype(int).tolist() == exp["is_active"]
-    if "obs0_agent0" in exp:
-        assert out["obs0"][0, 0].astype(int).tolist() == exp["obs0_agent0"]
+    check_spec_case(case, oracle_rollout if impl == "python" else c_oracle_rollout)
 
 
 def test_observation_planes_by_hand():

@@ -198,3 +198,75 @@ def test_helper_waves(geom, waves, monkeypatch):
         ref = oracle_rollout(obstacles, agents, targets, actions, **kw)
         got = engine_rollout(obstacles, agents, targets, actions, obs_dtype=torch.uint8 if u8 else None, **kw)
         assert_rollouts_equal(ref, got, f"helpers={waves}/{name}/{collision}/{on_target}")
+
+
+VARIANT_GEOMS = [g for g in GEOMETRIES if g[0] in ("baseline_cfg1", "dense_small", "full_wave", "odd_agents", "two_slots",
+                                                   "four_slots", "one_agent")]
+
+
+@pytest.mark.parametrize("geom", VARIANT_GEOMS, ids=[g[0] for g in VARIANT_GEOMS])
+@pytest.mark.parametrize("on_target", ON_TARGET)
+def test_semantics_variants(geom, on_target):
+    """The switches for the low-confidence recollections (docs/SPEC.md Q1 / Q4; pogema_amd.Semantics) in their
+    NON-default position -- soft 'all_stay', coop 'per_agent' -- engine vs the literal oracle, single- and multi-wave
+    environments, auto-reset on and off.  (The default position is every other test of this file.)"""
+    from pogema_amd import Semantics
+    name, B, H, Wd, A, r, density, T, max_steps = geom
+    seed = zlib.crc32(f"variants/{name}/{on_target}".encode()) % (2 ** 31)
+    obstacles, agents, targets = generate_instances(B, H, Wd, A, density, seed)
+    actions = random_actions(T, B, A, seed + 1)
+    sem = Semantics(soft_vertex="all_stay", coop_reward="per_agent")
+    for auto_reset in (False, True):
+        kw = dict(obs_radius=r, collision_system="soft", on_target=on_target, max_episode_steps=max_steps,
+                  auto_reset=auto_reset, seed=4321, env_index_base=9, semantics=sem)
+        ref = oracle_rollout(obstacles, agents, targets, actions, **kw)
+        got = engine_rollout(obstacles, agents, targets, actions, **kw)
+        assert_rollouts_equal(ref, got, f"variants/{name}/{on_target}/auto_reset={auto_reset}")
+
+
+@pytest.mark.parametrize("A", [8, 64, 200])
+def test_all_stay_chains_and_rotations(A):
+    """'all_stay' at the closure's extremes: a shoulder-to-shoulder line (free and blocked head) and crowds where
+    every contested cell must keep ALL its claimants out."""
+    from pogema_amd import Semantics
+    sem = Semantics(soft_vertex="all_stay")
+    rng = np.random.default_rng(A)
+    right = np.full((1, 1, A), 4, np.int64)
+    acts = np.concatenate([right, random_actions(5, 1, A, 11), right])
+    for blocked_front in (False, True):
+        for order in (np.arange(A), rng.permutation(A)):
+            obstacles, agents, targets = _corridor_case(A, order, blocked_front)
+            kw = dict(obs_radius=2, collision_system="soft", on_target="nothing", max_episode_steps=64, auto_reset=False,
+                      semantics=sem)
+            ref = oracle_rollout(obstacles, agents, targets, acts, **kw)
+            got = engine_rollout(obstacles, agents, targets, acts, **kw)
+            assert_rollouts_equal(ref, got, f"all_stay chain A={A} blocked={blocked_front}")
+
+
+def test_bad_actions_noop_and_flag():
+    """docs/SPEC.md Q7: out-of-range actions (every action dtype, negative and too large) are noops by default; with
+    Semantics(bad_action='flag') step() raises the reference's IndexError -- but only for ACTIVE agents."""
+    import torch
+    from pogema_amd import GridConfig, Semantics, VecPogema
+    B, H, Wd, A, r = 5, 9, 9, 6, 2
+    obstacles, agents, targets = generate_instances(B, H, Wd, A, 0.15, 77)
+    good = random_actions(6, B, A, 3)
+    bad = good.copy()
+    rng = np.random.default_rng(5)
+    mask = rng.random(bad.shape) < 0.3
+    bad[mask] = rng.choice([-7, -1, 5, 6, 100], size=int(mask.sum()))
+    cleaned = np.where((bad < 0) | (bad > 4), 0, bad)
+    for collision in COLLISIONS:
+        kw = dict(obs_radius=r, collision_system=collision, on_target="finish", max_episode_steps=64, auto_reset=False)
+        ref = oracle_rollout(obstacles, agents, targets, cleaned, **kw)
+        for dtype in ("int8", "int32", "int64"):
+            got = engine_rollout(obstacles, agents, targets, bad, action_dtype=dtype, **kw)
+            assert_rollouts_equal(ref, got, f"bad actions as noop/{collision}/{dtype}")
+    gc = GridConfig(map=obstacles[0].tolist(), num_agents=A, obs_radius=r, collision_system="soft")
+    env = VecPogema(gc, batch=B, semantics=Semantics(bad_action="flag"))
+    env.reset_from_state(obstacles, agents, targets)
+    env.step(torch.from_numpy(good[0]).cuda())  # in range: no error
+    with pytest.raises(IndexError):
+        env.step(torch.from_numpy(bad[1]).cuda())
+    env.step(torch.from_numpy(good[2]).cuda())  # the counter was cleared by the raise
+    env.close()

@@ -13,7 +13,7 @@ from util import assert_rollouts_equal, oracle_rollout, random_actions
 pytestmark = pytest.mark.gpu
 
 
-def _c_generate(B, H, W, A, density, key_base, epochs=None, given_map=None, max_retries=10):
+def _c_generate(B, H, W, A, density, seed, base=0, epochs=None, given_map=None, max_retries=10):
     lib = load_c_oracle()
     lib.po_generate.argtypes = [C.c_int32] * 4 + [C.c_float, C.c_uint64, C.c_int64, C.c_void_p, C.c_int32, C.c_int32,
                                                  C.c_void_p, C.c_void_p, C.c_void_p]
@@ -22,7 +22,7 @@ def _c_generate(B, H, W, A, density, key_base, epochs=None, given_map=None, max_
     a = np.empty((B, A, 2), np.int32)
     t = np.empty((B, A, 2), np.int32)
     ep = None if epochs is None else np.ascontiguousarray(epochs, np.uint32).ctypes.data
-    st = lib.po_generate(B, H, W, A, density, 0, key_base, ep, max_retries, int(given_map is not None),
+    st = lib.po_generate(B, H, W, A, density, seed, base, ep, max_retries, int(given_map is not None),
                          obst.ctypes.data, a.ctypes.data, t.ctypes.data)
     return st, obst, a, t
 
@@ -52,7 +52,7 @@ def test_device_reset_equals_python_oracle(cfg):
     env = VecPogema(gc, batch=B, env_index_base=base)
     obs, infos = env.reset(seed=seed)
     maps, agents, targets = _device_state(env)
-    ro, ra, rt = G.generate_batch(0, B, H, W, A, density, env_index_base=seed + base)
+    ro, ra, rt = G.generate_batch(seed, B, H, W, A, density, env_index_base=base)
     assert np.array_equal(maps, ro), f"{name}: obstacles"
     assert np.array_equal(agents, ra) and np.array_equal(targets, rt), f"{name}: placement"
     # the host generator of the product draws the same instances
@@ -92,7 +92,7 @@ def test_shared_map_and_masked_regeneration():
     env = VecPogema(gc, batch=B, env_index_base=base)
     env.reset(seed=seed)
     maps, agents, targets = _device_state(env)
-    ro, ra, rt = G.generate_batch(0, B, H, W, A, 0.0, env_index_base=seed + base, given_map=m)
+    ro, ra, rt = G.generate_batch(seed, B, H, W, A, 0.0, env_index_base=base, given_map=m)
     assert np.array_equal(maps, ro) and np.array_equal(agents, ra) and np.array_equal(targets, rt)
     # step a little, then regenerate a subset: flagged envs get generation 1, the others keep their state
     acts = torch.randint(0, 5, (B, A), device="cuda")
@@ -105,7 +105,7 @@ def test_shared_map_and_masked_regeneration():
     after = env.get_state()
     for b in range(B):
         if mask[b]:
-            _, ea, et = G.generate_instance(0, seed + base + b, H, W, A, 0.0, epoch=1, given_map=m)
+            _, ea, et = G.generate_instance(seed, base + b, H, W, A, 0.0, epoch=1, given_map=m)
             assert np.array_equal(after["agents_xy"][b].cpu().numpy(), ea)
             assert np.array_equal(after["targets_xy"][b].cpu().numpy(), et)
             assert int(after["elapsed"][b]) == 0 and bool(after["is_active"][b].all())
@@ -126,12 +126,12 @@ def test_masked_regeneration_random_maps_epoch2():
     env.reset_where(mask)  # generation 2 for envs 2 and 7
     maps, agents, targets = _device_state(env)
     for b in range(B):
-        eo, ea, et = G.generate_instance(0, seed + b, S, S, A, 0.25, epoch=2 if b in (2, 7) else 0)
+        eo, ea, et = G.generate_instance(seed, b, S, S, A, 0.25, epoch=2 if b in (2, 7) else 0)
         assert np.array_equal(maps[b], eo) and np.array_equal(agents[b], ea) and np.array_equal(targets[b], et), b
     # a full reset returns every env to generation 0
     env.reset(seed=seed)
     maps2, agents2, _ = _device_state(env)
-    eo, ea, _ = G.generate_instance(0, seed + 2, S, S, A, 0.25, epoch=0)
+    eo, ea, _ = G.generate_instance(seed, 2, S, S, A, 0.25, epoch=0)
     assert np.array_equal(maps2[2], eo) and np.array_equal(agents2[2], ea)
     env.close()
 
@@ -150,7 +150,7 @@ def test_full_size_device_reset_equals_c_oracle(cfg, on_target):
                     batch=B, env_index_base=base)
     env.reset(seed=seed)
     maps, agents, targets = _device_state(env)
-    st, ro, ra, rt = _c_generate(B, S, S, A, density, seed + base)
+    st, ro, ra, rt = _c_generate(B, S, S, A, density, seed, base)
     assert st == 0
     assert np.array_equal(maps, ro), f"{name}: obstacles"
     assert np.array_equal(agents, ra) and np.array_equal(targets, rt), f"{name}: placement"
@@ -180,7 +180,7 @@ def test_regenerate_mode_tracks_oracle(on_target, empty_outside):
     obs, _ = env.reset(seed=seed)
 
     def fresh(b, epoch):
-        o, a, t = G.generate_instance(0, seed + base + b, S, S, A, 0.25, epoch=epoch)
+        o, a, t = G.generate_instance(seed, base + b, S, S, A, 0.25, epoch=epoch)
         return PogemaOracle(o, a, t, obs_radius=r, collision_system="priority", on_target=on_target,
                             max_episode_steps=T, auto_reset=False, seed=seed, env_index=base + b,
                             empty_outside=empty_outside, outside_density=0.25, epoch=epoch)

@@ -37,8 +37,8 @@ def _worker(rank, world, port, tmpdir):
         GB, H, W, A, r, T = 11, 10, 10, 6, 3, 12  # global batch not divisible by the world size
         start, count = shard_bounds(GB, world, rank)
         seed = 321
-        # this rank's slice: env i is seeded with seed + i, exactly like VecPogema.generate()
-        obstacles, agents, targets = generate_instances(count, H, W, A, 0.2, seed + start)
+        # this rank's slice: global env i draws instance (seed, i), exactly like VecPogema.generate()
+        obstacles, agents, targets = generate_instances(count, H, W, A, 0.2, seed, env_index_base=start)
         actions = random_actions(T, GB, A, 5)[:, start:start + count]
         env = COracle(count, H, W, A, r, "soft", "restart", 5, True, seed=9, env_index_base=start)
         env.reset(obstacles, agents, targets)

@@ -15,14 +15,15 @@ if ROOT not in sys.path:
 from oracle.pogema_oracle import PogemaOracle  # noqa: E402
 
 
-def generate_instances(batch, height, width, num_agents, density, seed):
-    """Instances from the engine's HOST generator (pure host code; needs no GPU)."""
+def generate_instances(batch, height, width, num_agents, density, seed, env_index_base=0):
+    """Instances from the engine's HOST generator (pure host code; needs no GPU): env b is instance
+    (seed, env_index_base + b)."""
     from pogema_amd import _lib
     lib = _lib.load()
     obstacles = np.empty((batch, height, width), dtype=np.uint8)
     agents = np.empty((batch, num_agents, 2), dtype=np.int32)
     targets = np.empty((batch, num_agents, 2), dtype=np.int32)
-    _lib.check(lib.pgx_generate(batch, height, width, num_agents, float(density), int(seed), 50, 0,
+    _lib.check(lib.pgx_generate(batch, height, width, num_agents, float(density), int(seed), int(env_index_base), 50, 0,
                                 obstacles.ctypes.data, agents.ctypes.data, targets.ctypes.data))
     return obstacles, agents, targets
 
@@ -41,8 +42,13 @@ def outside_density_of(obstacles):
     return float(sum(1 for v in m.reshape(-1) if v != 0) / m.size)
 
 
+def _oracle_semantics(semantics):
+    """pogema_amd.Semantics (or None = defaults) -> the oracles' keyword arguments."""
+    return {} if semantics is None else semantics.oracle_kwargs()
+
+
 def oracle_rollout(obstacles, agents, targets, actions, *, obs_radius, collision_system, on_target,
-                   max_episode_steps, auto_reset, seed=0, env_index_base=0, empty_outside=True):
+                   max_episode_steps, auto_reset, seed=0, env_index_base=0, empty_outside=True, semantics=None):
     """Returns dict of arrays [T, B, ...] from the pure-Python oracle."""
     T, B, A = actions.shape
     W = 2 * obs_radius + 1
@@ -50,7 +56,8 @@ def oracle_rollout(obstacles, agents, targets, actions, *, obs_radius, collision
                          collision_system=collision_system, on_target=on_target,
                          max_episode_steps=max_episode_steps, auto_reset=auto_reset, seed=seed,
                          env_index=env_index_base + b, empty_outside=empty_outside,
-                         outside_density=outside_density_of(obstacles)) for b in range(B)]
+                         outside_density=outside_density_of(obstacles), **_oracle_semantics(semantics))
+            for b in range(B)]
     out = {
         "obs0": np.stack([np.stack(e._obs()) for e in envs]),
         "obs": np.zeros((T, B, A, 3, W, W), np.float32), "rewards": np.zeros((T, B, A), np.float32),
@@ -79,14 +86,16 @@ def oracle_rollout(obstacles, agents, targets, actions, *, obs_radius, collision
 
 
 def c_oracle_rollout(obstacles, agents, targets, actions, *, obs_radius, collision_system, on_target,
-                     max_episode_steps, auto_reset, seed=0, env_index_base=0, nthreads=1, empty_outside=True):
+                     max_episode_steps, auto_reset, seed=0, env_index_base=0, nthreads=1, empty_outside=True,
+                     semantics=None):
     """Same rollout through the plain-C oracle port (oracle/libpogema_oracle.so)."""
     from oracle.c_oracle import COracle
     T, B, A = actions.shape
     H, Wd = obstacles.shape[1:]
     W = 2 * obs_radius + 1
     env = COracle(B, H, Wd, A, obs_radius, collision_system, on_target, max_episode_steps, auto_reset, seed,
-                  env_index_base, empty_outside=empty_outside, outside_density=outside_density_of(obstacles))
+                  env_index_base, empty_outside=empty_outside, outside_density=outside_density_of(obstacles),
+                  **_oracle_semantics(semantics))
     out = {
         "obs0": env.reset(obstacles, agents, targets),
         "obs": np.zeros((T, B, A, 3, W, W), np.float32), "rewards": np.zeros((T, B, A), np.float32),
@@ -97,6 +106,9 @@ def c_oracle_rollout(obstacles, agents, targets, actions, *, obs_radius, collisi
     }
     for t in range(T):
         obs, rew, term, trunc, act = env.step(actions[t], nthreads=nthreads)
+        if env.bad_action_count():  # bad_action='flag': the port counts, the host raises (like the engine)
+            env.close()
+            raise IndexError("an active agent's action was outside 0..4")
         out["episode_done"][t] = env.episode_done.astype(bool)
         out["metrics"][t] = np.where(out["episode_done"][t][:, None], env.metrics, 0)
         st = env.get_state()
@@ -109,7 +121,7 @@ def c_oracle_rollout(obstacles, agents, targets, actions, *, obs_radius, collisi
 
 def engine_rollout(obstacles, agents, targets, actions, *, obs_radius, collision_system, on_target,
                    max_episode_steps, auto_reset, seed=0, env_index_base=0, action_dtype="int64",
-                   device="cuda:0", obs_dtype=None, empty_outside=True):
+                   device="cuda:0", obs_dtype=None, empty_outside=True, semantics=None):
     """Same rollout through the HIP engine (C-ABI via pogema_amd.VecPogema)."""
     import torch
     from pogema_amd import GridConfig, VecPogema
@@ -119,6 +131,8 @@ def engine_rollout(obstacles, agents, targets, actions, *, obs_radius, collision
                     collision_system=collision_system, on_target=on_target, max_episode_steps=max_episode_steps,
                     seed=seed, empty_outside=empty_outside)
     extra = {} if obs_dtype is None else {"obs_dtype": obs_dtype}
+    if semantics is not None:
+        extra["semantics"] = semantics
     env = VecPogema(gc, batch=B, device=device, auto_reset=auto_reset, env_index_base=env_index_base, **extra)
     obs0 = env.reset_from_state(obstacles, agents, targets)
     if obs_dtype is not None:
@@ -169,3 +183,32 @@ def assert_rollouts_equal(ref, got, what=""):
             bad = np.argwhere(ref[key] != got[key])[0]
             raise AssertionError(f"{what}: {key} differs first at index {tuple(bad)}: "
                                  f"oracle={ref[key][tuple(bad)]} engine={got[key][tuple(bad)]}")
+
+
+def check_spec_case(case, run):
+    """One hand-derived SPEC vector (tests/golden/spec_vectors.json) against `run` (oracle_rollout, c_oracle_rollout
+    or engine_rollout).  `case["semantics"]` selects non-default switches; `expect["raises"]` names the exception the
+    rollout must end with."""
+    import pytest
+    from pogema_amd.semantics import Semantics
+    obstacles = np.array(case["map"], np.uint8)[None]
+    agents = np.array(case["agents_xy"], np.int32)[None]
+    targets = np.array(case["targets_xy"], np.int32)[None]
+    actions = np.array(case["actions"], np.int64)[:, None, :]
+    kw = dict(obs_radius=case["obs_radius"], collision_system=case["collision_system"], on_target=case["on_target"],
+              max_episode_steps=case.get("max_episode_steps", 64), auto_reset=False,
+              semantics=Semantics(**case["semantics"]) if case.get("semantics") else None)
+    exp = case["expect"]
+    if "raises" in exp:
+        with pytest.raises({"IndexError": IndexError}[exp["raises"]]):
+            run(obstacles, agents, targets, actions, **kw)
+        return
+    out = run(obstacles, agents, targets, actions, **kw)
+    assert out["agents_xy"][:, 0].tolist() == exp["agents_xy"], case["why"]
+    if "rewards" in exp:
+        assert out["rewards"][:, 0].tolist() == exp["rewards"], case["why"]
+    for key in ("terminated", "truncated", "is_active"):
+        if key in exp:
+            assert out[key][:, 0].astype(int).tolist() == exp[key], f"{key}: {case['why']}"
+    if "obs0_agent0" in exp:
+        assert out["obs0"][0, 0].astype(int).tolist() == exp["obs0_agent0"]

@@ -15,10 +15,16 @@ NOOP, UP, DOWN, LEFT, RIGHT = 0, 1, 2, 3, 4
 cases = []
 
 
-def case(name, why, map_, agents, targets, actions, collision, expect, on_target="finish", r=1, max_steps=64):
-    cases.append(dict(name=f"{name}-{collision}", why=why, map=map_, agents_xy=agents, targets_xy=targets,
-                      actions=actions, collision_system=collision, on_target=on_target, obs_radius=r,
-                      max_episode_steps=max_steps, expect=expect))
+def case(name, why, map_, agents, targets, actions, collision, expect, on_target="finish", r=1, max_steps=64,
+         semantics=None):
+    """`semantics`: non-default switches of pogema_amd.Semantics (docs/SPEC.md Q1 / Q4 / Q7) this case runs under."""
+    tag = "" if not semantics else "/" + ",".join(f"{k}={v}" for k, v in sorted(semantics.items()))
+    c = dict(name=f"{name}-{collision}{tag}", why=why, map=map_, agents_xy=agents, targets_xy=targets,
+             actions=actions, collision_system=collision, on_target=on_target, obs_radius=r,
+             max_episode_steps=max_steps, expect=expect)
+    if semantics:
+        c["semantics"] = semantics
+    cases.append(c)
 
 
 far = [[2, 2], [2, 0]]
@@ -89,6 +95,45 @@ case("coop_finish", "A8: nothing happens on a goal until ALL agents stand on the
      OPEN3, [[0, 0], [2, 2]], [[0, 1], [2, 0]], [[RIGHT, LEFT], [NOOP, LEFT]], "priority",
      dict(agents_xy=[[[0, 1], [2, 1]], [[0, 1], [2, 0]]], rewards=[[0.0, 0.0], [1.0, 1.0]], terminated=[[0, 0], [1, 1]],
           is_active=[[1, 1], [1, 1]]), on_target="nothing")
+
+# --- the switches for the low-confidence recollections (docs/SPEC.md Q1, Q4, Q7): both values of each ---------
+ALL_STAY = {"soft_vertex": "all_stay"}
+case("vertex", "Q1 alternative: both claimants of the free cell (0,1) stay", OPEN3, [[0, 0], [0, 2]], far,
+     [[RIGHT, LEFT]], "soft", dict(agents_xy=[[[0, 0], [0, 2]]]), semantics=ALL_STAY)
+case("three_way", "Q1 alternative: all three claimants of (1,1) stay; agent 3 moves into the cell of agent 2, which "
+     "stays, so 3 stays as well", [[0, 0, 0, 0], [0, 0, 0, 0], [0, 0, 0, 0]], [[0, 1], [1, 0], [1, 2], [1, 3]],
+     [[2, 3], [2, 2], [2, 1], [2, 0]], [[DOWN, RIGHT, LEFT, LEFT]], "soft",
+     dict(agents_xy=[[[0, 1], [1, 0], [1, 2], [1, 3]]]), semantics=ALL_STAY)
+vac_agents = [[1, 1], [1, 0], [1, 2]]
+vac_targets = [[0, 0], [0, 2], [2, 0]]
+case("vacated_contest", "Q1 literal: agent 0 leaves (1,1) downwards; 1 and 2 both claim the vacated cell; the "
+     "reverse-index loop reverts 2, agent 1 is then the only claimant and follows into (1,1)",
+     OPEN3, vac_agents, vac_targets, [[DOWN, RIGHT, LEFT]], "soft", dict(agents_xy=[[[2, 1], [1, 1], [1, 2]]]))
+case("vacated_contest", "Q1 alternative: the vacated cell is contested, so both claimants stay; the leaver moves",
+     OPEN3, vac_agents, vac_targets, [[DOWN, RIGHT, LEFT]], "soft", dict(agents_xy=[[[2, 1], [1, 0], [1, 2]]]),
+     semantics=ALL_STAY)
+ROW5 = [[0, 0, 0, 0, 0]]
+cas_agents = [[0, 1], [0, 3], [0, 0]]
+cas_targets = [[0, 4], [0, 0], [0, 3]]
+case("contest_then_follow", "Q1 literal: 0 and 1 claim (0,2): index 0 wins and moves, 1 stays; 2 follows into the cell "
+     "0 vacated", ROW5, cas_agents, cas_targets, [[RIGHT, LEFT, RIGHT]], "soft",
+     dict(agents_xy=[[[0, 2], [0, 3], [0, 1]]]))
+case("contest_then_follow", "Q1 alternative: 0 and 1 both stay; 2 wants the cell of 0, which stays, so 2 stays too "
+     "(second round of the fixed point)", ROW5, cas_agents, cas_targets, [[RIGHT, LEFT, RIGHT]], "soft",
+     dict(agents_xy=[[[0, 1], [0, 3], [0, 0]]]), semantics=ALL_STAY)
+case("coop_finish", "Q4 alternative: each agent is paid 1.0 in every step it stands on its own goal; the episode still "
+     "terminates only when all do", OPEN3, [[0, 0], [2, 2]], [[0, 1], [2, 0]], [[RIGHT, LEFT], [NOOP, LEFT]], "priority",
+     dict(agents_xy=[[[0, 1], [2, 1]], [[0, 1], [2, 0]]], rewards=[[1.0, 0.0], [1.0, 1.0]], terminated=[[0, 0], [1, 1]],
+          is_active=[[1, 1], [1, 1]]), on_target="nothing", semantics={"coop_reward": "per_agent"})
+for cs in ("priority", "block_both", "soft"):
+    case("bad_action", "Q7 default: actions outside 0..4 (too large or negative) do nothing", OPEN3, [[0, 0], [2, 2]],
+         far, [[7, -3], [RIGHT, 5]], cs, dict(agents_xy=[[[0, 0], [2, 2]], [[0, 1], [2, 2]]]))
+    case("bad_action", "Q7 alternative: an out-of-range action of an ACTIVE agent raises the reference's IndexError",
+         OPEN3, [[0, 0], [2, 2]], far, [[RIGHT, 5]], cs, dict(raises="IndexError"), semantics={"bad_action": "flag"})
+case("bad_action_inactive", "Q7 alternative: a finished (hidden) agent's action is never looked at (the reference guards "
+     "every MOVES[action] with is_active), so its garbage action raises nothing",
+     OPEN3, [[0, 0], [0, 2]], [[0, 1], [2, 2]], [[RIGHT, NOOP], [9, DOWN]], "priority",
+     dict(agents_xy=[[[0, 1], [0, 2]], [[0, 1], [1, 2]]], is_active=[[0, 1], [0, 1]]), semantics={"bad_action": "flag"})
 
 out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "spec_vectors.json")
 with open(out, "w") as f:

@@ -223,11 +223,13 @@ class EngineStep:
             self.i += 1
 
     def describe_buffers(self):
-        pu = getattr(self.env, "placement_us", None)
-        if pu:
-            return (f"2 alternating buffers, the fastest of {len(pu)} placement-probed candidates (observation pass "
-                    f"{pu[0]:.1f} / {pu[1]:.1f} us; slowest candidate {pu[-1]:.1f} us)")
-        return "2 alternating buffers as the allocator returned them (no placement probe)"
+        pl = getattr(self.env, "placement", None) or {}
+        if pl.get("method", "").startswith("pgx_buffers"):
+            return (f"2 alternating buffers from the engine's zone-aware pool: halves in two HBM zones = {pl['spread']} "
+                    f"(probe stream {pl['same_zone_us']:.1f} us same-zone -> {pl['final_us']:.1f} us as placed, "
+                    f"{pl['candidates']} candidates, {pl['spacer_gib']:.0f} GiB of temporary spacers; plain store stream "
+                    f"into buffer 0: {pl['buffer_gbs']:.0f} GB/s)")
+        return "2 alternating buffers as torch's allocator returned them (no zone placement)"
 
     def close(self):
         self.env.close()
@@ -355,10 +357,11 @@ def main(argv=None):
             step.run(args.steps)
             if not args.stub:
                 ev1.record()
+            own = time.perf_counter() - t0  # stub only: this rank's own time, before the closing barrier
             barrier()
             dt = time.perf_counter() - t0
             walls.append(reduce_max(dt))
-            kernel.append(ev0.elapsed_time(ev1) / args.steps if not args.stub else dt / args.steps * 1e3)
+            kernel.append(ev0.elapsed_time(ev1) / args.steps if not args.stub else own / args.steps * 1e3)
         return walls, kernel
 
     # the default-allocator placement first, in a fresh address space (before the probe's candidates exist)

@@ -209,6 +209,37 @@ int pgx_observe(pgx_env* env, void* obs, void* stream);
  * Synchronises `stream`.  Nothing in the engine's state changes. */
 int pgx_time_observe(pgx_env* env, void* obs, int32_t reps, float* microseconds, void* stream);
 
+/* ---- zone-aware output buffers ------------------------------------------------------------------ */
+/* Nothing in the reference corresponds to this: it is where the caller-owned observation buffers SHOULD live on an
+ * MI355X.  Physical HBM falls into a few large zones (tens of GiB; three on the devices measured).  A store stream
+ * confined to one zone sustains ~5.5 TB/s, the same stream with half of its bytes in another zone ~6.9 TB/s
+ * (profiles/r2/placement_*.txt); a plain hipMalloc'd buffer is physically compact and therefore lies in one zone
+ * unless it straddles a boundary by luck.  pgx_buffers_create returns `count` buffers of `bytes` bytes, each ONE
+ * contiguous virtual range (HIP virtual-memory API) whose second half is backed by physical memory from another zone:
+ * the allocator is walked there with temporary spacer allocations (at most `max_spacer_gib` GiB and 90 % of the free
+ * memory, released before the call returns) and every candidate is verified by timing a store stream into the buffer.
+ * The call synchronises the device (it times kernels on the default stream); it takes ~0.1-1 s.
+ *   max_spacer_gib <= 0  no search: the halves come from wherever the allocator is (still valid buffers)
+ * Buffers are usable by any kernel / copy like hipMalloc'd memory and stay valid until pgx_buffers_destroy. */
+typedef struct pgx_buffers pgx_buffers; /* opaque */
+typedef struct pgx_buffers_info {
+    int64_t bytes;        /* usable bytes per buffer                                                         */
+    int32_t count;
+    int32_t spread;       /* 1: the two halves of every buffer lie in different zones (verified by timing)   */
+    int32_t candidates;   /* second-half candidates timed                                                    */
+    int32_t reserved0;
+    float same_zone_us;   /* probe stream (768 MiB) into two halves allocated back to back (same zone)       */
+    float final_us;       /* probe stream with the second half taken where the buffers' second halves are      */
+    double spacer_gib;    /* spacer memory held at the end of the search (released before returning)          */
+    float buffer_gbs;     /* store-stream rate into buffer 0 as returned (0 when the buffer is below 256 MiB:   */
+                          /* such a stream is absorbed by the Infinity Cache and says nothing about placement)  */
+    float reserved1;
+} pgx_buffers_info;
+int pgx_buffers_create(int device, size_t bytes, int count, double max_spacer_gib, pgx_buffers** out);
+void* pgx_buffers_ptr(pgx_buffers* pool, int index); /* device pointer of buffer `index`, NULL if out of range */
+int pgx_buffers_get_info(pgx_buffers* pool, pgx_buffers_info* info);
+int pgx_buffers_destroy(pgx_buffers* pool);          /* synchronises the device, then unmaps and frees        */
+
 /* ---- state export ------------------------------------------------------------------------------- */
 /* Replaces `Grid.get_agents_xy` / `get_targets_xy` / `is_active` / the occupancy array (`positions`).
  * Any pointer may be NULL.  All device pointers.

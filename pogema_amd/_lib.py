@@ -49,6 +49,7 @@ EXPORTED_SYMBOLS = (
     "pgx_abi_version", "pgx_last_error", "pgx_create", "pgx_destroy", "pgx_obs_elems", "pgx_agent_elems",
     "pgx_reset_from_state", "pgx_reset_random", "pgx_regenerate", "pgx_regenerate_failures", "pgx_get_map", "pgx_step", "pgx_observe", "pgx_set_metrics_buffers", "pgx_get_state", "pgx_generate", "pgx_place_agents",
     "pgx_snapshot_bytes", "pgx_save_snapshot", "pgx_load_snapshot", "pgx_time_observe", "pgx_bad_action_count",
+    "pgx_buffers_create", "pgx_buffers_ptr", "pgx_buffers_get_info", "pgx_buffers_destroy",
 )
 
 
@@ -56,6 +57,12 @@ class PgxError(RuntimeError):
     def __init__(self, code: int, message: str):
         super().__init__(f"pogema_amd engine error {code}: {message}")
         self.code = code
+
+
+class PgxBuffersInfo(C.Structure):
+    _fields_ = [("bytes", C.c_int64), ("count", C.c_int32), ("spread", C.c_int32), ("candidates", C.c_int32),
+                ("reserved0", C.c_int32), ("same_zone_us", C.c_float), ("final_us", C.c_float), ("spacer_gib", C.c_double),
+                ("buffer_gbs", C.c_float), ("reserved1", C.c_float)]
 
 
 class PgxConfig(C.Structure):
@@ -104,6 +111,14 @@ def load() -> C.CDLL:
     lib.pgx_regenerate_failures.argtypes = [vp, vp]
     lib.pgx_regenerate_failures.restype = i64
     lib.pgx_get_map.argtypes = [vp, vp, vp]
+    lib.pgx_buffers_create.argtypes = [C.c_int, C.c_size_t, C.c_int, C.c_double, C.POINTER(vp)]
+    lib.pgx_buffers_create.restype = C.c_int
+    lib.pgx_buffers_ptr.argtypes = [vp, C.c_int]
+    lib.pgx_buffers_ptr.restype = vp
+    lib.pgx_buffers_get_info.argtypes = [vp, C.POINTER(PgxBuffersInfo)]
+    lib.pgx_buffers_get_info.restype = C.c_int
+    lib.pgx_buffers_destroy.argtypes = [vp]
+    lib.pgx_buffers_destroy.restype = C.c_int
     lib.pgx_bad_action_count.argtypes = [vp, vp]
     lib.pgx_bad_action_count.restype = i64
     lib.pgx_time_observe.argtypes = [vp, vp, i32, C.POINTER(C.c_float), vp]

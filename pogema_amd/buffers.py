@@ -1,0 +1,77 @@
+"""Zone-aware observation buffers (pgx_buffers_* of the C-ABI) as torch tensors.
+
+On MI355X a store stream confined to one physical zone of HBM sustains ~5.5 TB/s, the same stream with half of its
+bytes in another zone ~6.9 TB/s (DESIGN.md "placement"; profiles/r2/placement_*.txt).  `ZoneBuffers` asks the engine
+for buffers whose two halves are backed by different zones (one contiguous virtual range each) and exposes them as
+torch tensors through `__cuda_array_interface__` -- torch only wraps the pointer, the memory belongs to the pool and is
+released when the last tensor AND the pool object are gone.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_TYPESTR = {torch.float32: "<f4", torch.uint8: "|u1"}
+
+
+class _Owner:
+    """Keeps the native pool alive; destroyed (device synchronised, memory unmapped) when unreferenced."""
+
+    def __init__(self, lib, handle):
+        self._lib, self._handle = lib, handle
+
+    def __del__(self):
+        try:
+            if self._handle is not None and self._handle.value:
+                self._lib.pgx_buffers_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+
+class _Cai:
+    def __init__(self, ptr, shape, typestr, owner):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+        self._owner = owner  # the tensor references this object, this object references the pool
+
+
+class ZoneBuffers:
+    """`count` buffers of `shape`/`dtype` on `device`, each spread over two HBM zones when reachable.
+
+    max_spacer_gib: memory the search may hold temporarily while it walks the allocator into another zone (released
+    before the constructor returns); default PGX_ZONE_SPACER_GIB or 128; 0 disables the search."""
+
+    def __init__(self, shape, dtype, device, count=2, max_spacer_gib=None):
+        if dtype not in _TYPESTR:
+            raise ValueError(f"unsupported dtype {dtype}")
+        dev = torch.device(device)
+        index = dev.index if dev.index is not None else torch.cuda.current_device()
+        if max_spacer_gib is None:
+            max_spacer_gib = float(os.environ.get("PGX_ZONE_SPACER_GIB", "128"))
+        lib = _lib.load()
+        nbytes = int(np.prod(shape)) * (4 if dtype == torch.float32 else 1)
+        handle = C.c_void_p()
+        torch.cuda.synchronize(index)  # the search times kernels on the default stream
+        _lib.check(lib.pgx_buffers_create(index, nbytes, int(count), float(max_spacer_gib), C.byref(handle)))
+        self._owner = _Owner(lib, handle)
+        info = _lib.PgxBuffersInfo()
+        _lib.check(lib.pgx_buffers_get_info(handle, C.byref(info)))
+        self.info = {"spread": bool(info.spread), "candidates": int(info.candidates),
+                     "same_zone_us": round(float(info.same_zone_us), 2), "final_us": round(float(info.final_us), 2),
+                     "spacer_gib": float(info.spacer_gib), "bytes": int(info.bytes), "count": int(info.count),
+                     "buffer_gbs": round(float(info.buffer_gbs), 1)}
+        self.tensors = []
+        for i in range(count):
+            ptr = lib.pgx_buffers_ptr(handle, i)
+            if not ptr:
+                raise RuntimeError("pgx_buffers_ptr returned NULL")
+            t = torch.as_tensor(_Cai(ptr, shape, _TYPESTR[dtype], self._owner), device=torch.device("cuda", index))
+            if t.data_ptr() != ptr:
+                raise RuntimeError("torch copied the zone buffer instead of wrapping it")
+            self.tensors.append(t)

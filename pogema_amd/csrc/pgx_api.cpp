@@ -39,6 +39,23 @@ int fail(int code, const char* fmt, ...) {
             return fail(PGX_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
     } while (0)
 
+}  // namespace
+
+namespace pgx {
+// error reporting for the other translation units of the library (pgx_buffers.hip)
+int fail_msg(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+}  // namespace pgx
+
+namespace {
+
 struct DeviceGuard {
     int prev = -1;
     bool changed = false;
@@ -144,6 +161,10 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
     e->geo = pgx::step_geometry(cfg->batch, A, e->bmw, e->W, !(e->flags & 2u), epw_override,
                                 cfg->obs_dtype == PGX_OBS_U8 ? 1 : 4, waves_override);
     if (const char* f = getenv("PGX_STAGGER")) e->geo.stagger = atoi(f);  // tuning/diagnostic override
+    if (const char* f = getenv("PGX_LDS_MIN")) {  // diagnostic: cap residency by reserving LDS per workgroup
+        const size_t m = (size_t)atol(f);
+        if (m > e->geo.lds_bytes) e->geo.lds_bytes = (m + 15) & ~(size_t)15;
+    }
     if (e->geo.lds_bytes > 160 * 1024) {
         const size_t need = e->geo.lds_bytes;
         delete e;

@@ -1,0 +1,333 @@
+// pgx_buffers.hip -- zone-aware allocation of the large output (observation) buffers.
+//
+// Measured on MI355X (profiles/r2/placement_*.txt, tools/placement_zones.hip, tools/placement_layouts.hip): physical HBM
+// falls into a few large zones (three on the boxes measured, tens of GiB each -- consistent with the three 4-high rank
+// groups of the 12-high HBM3E stacks, 288 GiB / 3).  A pure store stream whose 761 MB all lie in ONE zone sustains
+// ~5.5 TB/s (138 us); the same stream with its first half in one zone and its second half in another sustains ~6.9 TB/s
+// (110 us) -- reads do not care.  One hipMalloc'd buffer is physically compact, so it lies in one zone unless it
+// happens to straddle a zone boundary: that was round 1's "placement lottery" (speed tiers 124 / 137 / 150 us).
+//
+// Here the placement is REQUESTED instead of searched for: a buffer is one contiguous virtual range assembled with the
+// HIP virtual-memory API from two physical halves, and the second half is taken from another zone.  Physical addresses
+// are not visible to user space, so "another zone" is found by moving the allocator: spacer allocations are held while
+// candidate second halves are created, each candidate is timed against the first half with a plain store stream, and
+// the first one that makes the stream >= 10 % faster than a same-zone pair is kept.  Spacers are released afterwards;
+// what stays allocated is exactly the buffers.  When no other zone is reachable (spacer budget, little free memory)
+// the buffers are still valid, just not spread -- pgx_buffers_info says which.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/pogema_amd.h"
+
+namespace pgx {
+// defined in pgx_api.cpp
+int fail_msg(int code, const char* fmt, ...);
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Store stream used to classify placements: `nblk` single-wave workgroups, each writes one contiguous chunk, the
+// chunks of one XCD contiguous in memory -- the shape of the step kernel's observation stream.
+// The first half of the chunks goes to `lo`, the second half to `hi` (two separate allocations: no virtual contiguity
+// needed for the probe).
+__global__ __launch_bounds__(64) void zone_probe_kernel(f32x4* __restrict__ lo, f32x4* __restrict__ hi, size_t per_block, int nblk) {
+    const f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    const int per_xcd = nblk >> 3;
+    int b = blockIdx.x;
+    if (b < (per_xcd << 3)) b = (b & 7) * per_xcd + (b >> 3);
+    const int half = nblk >> 1;
+    f32x4* o = b < half ? lo + (size_t)b * per_block : hi + (size_t)(b - half) * per_block;
+    for (size_t i = threadIdx.x; i < per_block; i += 64) o[i] = v;
+}
+}  // namespace pgx
+
+namespace {
+
+constexpr size_t GRANULE = (size_t)2 << 20;      // physical handles and virtual ranges are multiples of 2 MiB
+constexpr size_t GiB = (size_t)1 << 30;
+constexpr size_t PROBE_HALF = (size_t)384 << 20; // zone probe: two halves of 384 MiB (well beyond the 256 MiB Infinity Cache)
+constexpr size_t SPACER = 8 * GiB;
+
+size_t round_up(size_t v, size_t g) { return (v + g - 1) / g * g; }
+
+// One physical allocation mapped at a fixed virtual address.  hipMemSetAccess is issued by the caller over the WHOLE
+// virtual range once every part of it is mapped (per-part calls fail with "invalid argument" for some size pairs on
+// ROCm 7.2).
+struct Part {
+    hipMemGenericAllocationHandle_t handle{};
+    void* va = nullptr;
+    size_t bytes = 0;
+    bool live = false;
+};
+
+hipMemAllocationProp device_prop(int device) {
+    hipMemAllocationProp p = {};
+    p.type = hipMemAllocationTypePinned;
+    p.location.type = hipMemLocationTypeDevice;
+    p.location.id = device;
+    return p;
+}
+
+hipError_t map_part(int device, void* va, size_t bytes, Part& part) {
+    const hipMemAllocationProp prop = device_prop(device);
+    hipError_t e = hipMemCreate(&part.handle, bytes, &prop, 0);
+    if (e != hipSuccess) return e;
+    e = hipMemMap(va, bytes, 0, part.handle, 0);
+    if (e != hipSuccess) {
+        (void)hipMemRelease(part.handle);
+        return e;
+    }
+    part.va = va;
+    part.bytes = bytes;
+    part.live = true;
+    return hipSuccess;
+}
+
+hipError_t grant_access(int device, void* va, size_t bytes) {
+    hipMemAccessDesc acc = {};
+    acc.location = device_prop(device).location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    return hipMemSetAccess(va, bytes, &acc, 1);
+}
+
+void drop_part(Part& part) {
+    if (!part.live) return;
+    (void)hipMemUnmap(part.va, part.bytes);
+    (void)hipMemRelease(part.handle);
+    part.live = false;
+}
+
+// a virtual range that owns its parts
+struct Range {
+    void* va = nullptr;
+    size_t bytes = 0;
+    std::vector<Part> parts;
+    hipError_t reserve(size_t n) {
+        bytes = n;
+        const hipError_t e = hipMemAddressReserve(&va, n, GRANULE, nullptr, 0);
+        if (e != hipSuccess) va = nullptr;
+        return e;
+    }
+    void release() {
+        for (Part& p : parts) drop_part(p);
+        parts.clear();
+        if (va) (void)hipMemAddressFree(va, bytes);
+        va = nullptr;
+    }
+};
+
+}  // namespace
+
+struct pgx_buffers {
+    int device = 0;
+    size_t bytes = 0, first = 0, second = 0;  // requested bytes; sizes of the two physical halves
+    int count = 0;
+    std::vector<Range> buf;
+    pgx_buffers_info info{};
+};
+
+namespace {
+
+// average duration of the probe stream: `half_bytes` into `lo` and `half_bytes` into `hi`, concurrently
+hipError_t probe_us(void* lo, void* hi, size_t half_bytes, float* us) {
+    const int nblk = 8192;
+    const size_t per_block = half_bytes / 16 / (nblk / 2);
+    hipEvent_t a, b;
+    hipError_t e = hipEventCreate(&a);
+    if (e != hipSuccess) return e;
+    e = hipEventCreate(&b);
+    if (e != hipSuccess) {
+        (void)hipEventDestroy(a);
+        return e;
+    }
+    (void)hipGetLastError();
+    const int reps = 6;
+    for (int i = 0; i < 2; ++i)
+        hipLaunchKernelGGL(pgx::zone_probe_kernel, dim3(nblk), dim3(64), 0, 0, (pgx::f32x4*)lo, (pgx::f32x4*)hi, per_block, nblk);
+    (void)hipEventRecord(a, 0);
+    for (int i = 0; i < reps; ++i)
+        hipLaunchKernelGGL(pgx::zone_probe_kernel, dim3(nblk), dim3(64), 0, 0, (pgx::f32x4*)lo, (pgx::f32x4*)hi, per_block, nblk);
+    (void)hipEventRecord(b, 0);
+    e = hipEventSynchronize(b);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    if (e == hipSuccess) e = hipGetLastError();
+    *us = ms * 1000.f / reps;
+    return e;
+}
+
+void destroy(pgx_buffers* p) {
+    for (Range& r : p->buf) r.release();
+    delete p;
+}
+
+// one allocation of `bytes` at its own virtual address, accessible
+hipError_t make_chunk(int device, size_t bytes, Range& r) {
+    hipError_t e = r.reserve(bytes);
+    if (e != hipSuccess) return e;
+    r.parts.resize(1);
+    e = map_part(device, r.va, bytes, r.parts[0]);
+    if (e == hipSuccess) e = grant_access(device, r.va, bytes);
+    if (e != hipSuccess) r.release();
+    return e;
+}
+
+// Walks the allocator into another zone.  A reference chunk is allocated first (right behind the buffers' first
+// halves: their zone); then, after every spacer, a candidate chunk; the probe stream writes half of its bytes into the
+// reference and half into the candidate.  Nothing is freed during the walk (a freed chunk would be handed out again
+// and the walk would stand still): `held` keeps spacers, reference and candidates until the caller has allocated the
+// second halves.  On return with *found the allocator sits right behind a candidate that lies in another zone.
+void find_other_zone(int device, size_t budget, std::vector<Range>& held, pgx_buffers_info& info, bool* found) {
+    *found = false;
+    held.emplace_back();
+    if (make_chunk(device, PROBE_HALF, held.back()) != hipSuccess) { held.pop_back(); return; }
+    void* ref = held.back().va;
+    held.emplace_back();
+    if (make_chunk(device, PROBE_HALF, held.back()) != hipSuccess) { held.pop_back(); return; }
+    float t_same = 0.f;
+    if (probe_us(ref, held.back().va, PROBE_HALF, &t_same) != hipSuccess) return;
+    info.same_zone_us = info.final_us = t_same;
+    // A one-zone stream sustains 5.5-6.0 TB/s on every device measured, a two-zone stream 6.7-7.9 TB/s: a pair that
+    // already exceeds 6.3 TB/s straddles a zone boundary as it is -- the allocator stands in the other zone already.
+    const float t_spread_abs = (float)(2.0 * (double)PROBE_HALF / 6.3e12 * 1e6);
+    if (t_same <= t_spread_abs) {
+        *found = true;
+        return;
+    }
+    size_t spacer_bytes = 0;
+    while (spacer_bytes + SPACER <= budget) {
+        held.emplace_back();
+        if (make_chunk(device, SPACER, held.back()) != hipSuccess) { held.pop_back(); (void)hipGetLastError(); break; }
+        spacer_bytes += SPACER;
+        info.spacer_gib = (double)spacer_bytes / (double)GiB;
+        held.emplace_back();
+        if (make_chunk(device, PROBE_HALF, held.back()) != hipSuccess) { held.pop_back(); (void)hipGetLastError(); break; }
+        float t = 0.f;
+        if (probe_us(ref, held.back().va, PROBE_HALF, &t) != hipSuccess) break;
+        info.candidates += 1;
+        if (t < 0.9f * t_same || t <= t_spread_abs) {
+            info.final_us = t;
+            *found = true;
+            // the first faster candidate may itself straddle the boundary: one more spacer puts what is allocated
+            // next safely inside the new zone (zones are tens of GiB wide)
+            if (spacer_bytes + SPACER <= budget) {
+                held.emplace_back();
+                if (make_chunk(device, SPACER, held.back()) != hipSuccess) { held.pop_back(); (void)hipGetLastError(); return; }
+                spacer_bytes += SPACER;
+                info.spacer_gib = (double)spacer_bytes / (double)GiB;
+                held.emplace_back();
+                if (make_chunk(device, PROBE_HALF, held.back()) != hipSuccess) { held.pop_back(); (void)hipGetLastError(); return; }
+                if (probe_us(ref, held.back().va, PROBE_HALF, &t) == hipSuccess) {
+                    info.candidates += 1;
+                    info.final_us = t;
+                }
+            }
+            return;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pgx_buffers_create(int device, size_t bytes, int count, double max_spacer_gib, pgx_buffers** out) {
+    if (!out) return pgx::fail_msg(PGX_E_INVALID, "pgx_buffers_create: null argument");
+    *out = nullptr;
+    if (bytes == 0 || count < 1 || count > 64) return pgx::fail_msg(PGX_E_INVALID, "pgx_buffers_create: bad size or count");
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(device) != hipSuccess)
+        return pgx::fail_msg(PGX_E_HIP, "cannot select HIP device %d", device);
+    pgx_buffers* p = new (std::nothrow) pgx_buffers();
+    if (!p) return pgx::fail_msg(PGX_E_NOMEM, "out of host memory");
+    p->device = device;
+    p->bytes = bytes;
+    p->count = count;
+    const size_t total = round_up(bytes, GRANULE);
+    p->first = total >= 2 * GRANULE ? round_up(total / 2, GRANULE) : total;
+    p->second = total - p->first;
+    p->buf.resize(count);
+    p->info.bytes = (int64_t)bytes;
+    p->info.count = count;
+    std::vector<Range> held;  // spacers, reference and candidate chunks of the zone walk
+    auto bail = [&](int code, const char* what, hipError_t e) {
+        const std::string msg = std::string(what) + ": " + hipGetErrorString(e);
+        for (Range& s : held) s.release();
+        destroy(p);
+        (void)hipGetLastError();
+        (void)hipSetDevice(prev);
+        return pgx::fail_msg(code, "%s", msg.c_str());
+    };
+    auto code_of = [](hipError_t e) { return e == hipErrorOutOfMemory ? PGX_E_NOMEM : PGX_E_HIP; };
+    // 1. virtual ranges + first halves (the zone the allocator is in right now)
+    for (int i = 0; i < count; ++i) {
+        hipError_t e = p->buf[i].reserve(total);
+        if (e != hipSuccess) return bail(PGX_E_NOMEM, "hipMemAddressReserve", e);
+        p->buf[i].parts.resize(p->second ? 2 : 1);
+        e = map_part(device, p->buf[i].va, p->first, p->buf[i].parts[0]);
+        if (e != hipSuccess) return bail(code_of(e), "hipMemCreate/hipMemMap (first half)", e);
+    }
+    // 2. walk the allocator into another zone (worth it for streams that are bandwidth-bound: buffers >= 16 MiB)
+    bool found = false;
+    if (p->second && total >= ((size_t)16 << 20) && max_spacer_gib > 0.0) {
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        const size_t need = (size_t)count * p->second + 20 * PROBE_HALF + 4 * GiB;
+        size_t budget = (size_t)(max_spacer_gib * (double)GiB);
+        budget = std::min(budget, free_b > need ? (free_b - need) / 10 * 9 : 0);
+        find_other_zone(device, budget, held, p->info, &found);
+        (void)hipGetLastError();
+    }
+    // 3. second halves, right behind the last candidate of the walk (everything the walk allocated is still held)
+    for (int i = 0; i < count && p->second; ++i) {
+        const hipError_t e = map_part(device, (char*)p->buf[i].va + p->first, p->second, p->buf[i].parts[1]);
+        if (e != hipSuccess) return bail(code_of(e), "hipMemCreate/hipMemMap (second half)", e);
+    }
+    for (int i = 0; i < count; ++i) {
+        const hipError_t e = grant_access(device, p->buf[i].va, total);
+        if (e != hipSuccess) return bail(PGX_E_HIP, "hipMemSetAccess", e);
+    }
+    for (Range& s : held) s.release();
+    p->info.spread = found ? 1 : 0;
+    if (p->second && total >= ((size_t)256 << 20)) {
+        float t = 0.f;
+        if (probe_us(p->buf[0].va, (char*)p->buf[0].va + p->first, p->second, &t) == hipSuccess && t > 0.f)
+            p->info.buffer_gbs = (float)(2.0 * (double)p->second / ((double)t * 1e-6) / 1e9);
+    }
+    (void)hipGetLastError();
+    *out = p;
+    (void)hipSetDevice(prev);
+    return PGX_OK;
+}
+
+void* pgx_buffers_ptr(pgx_buffers* p, int index) {
+    if (!p || index < 0 || index >= p->count) return nullptr;
+    return p->buf[index].va;
+}
+
+int pgx_buffers_get_info(pgx_buffers* p, pgx_buffers_info* info) {
+    if (!p || !info) return pgx::fail_msg(PGX_E_INVALID, "pgx_buffers_get_info: null argument");
+    *info = p->info;
+    return PGX_OK;
+}
+
+int pgx_buffers_destroy(pgx_buffers* p) {
+    if (!p) return PGX_OK;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(p->device);
+    (void)hipDeviceSynchronize();  // nothing may still be writing into the ranges that are about to be unmapped
+    destroy(p);
+    if (prev >= 0) (void)hipSetDevice(prev);
+    return PGX_OK;
+}
+
+}  // extern "C"

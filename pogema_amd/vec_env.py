@@ -310,40 +310,24 @@ class VecPogema:
                 torch.empty((B, A), dtype=torch.bool, device=dev),
                 torch.empty((B, A), dtype=torch.bool, device=dev))
 
-    # Placement of the double-buffered observation tensors (reuse_buffers=True).  Equal hipMalloc'd buffers fall into
-    # speed tiers on MI355X (~140 / ~144 / ~153 us per configs[2] step on one device, profiles/r1/placement_tiers.txt):
-    # where the physical pages live matters.  The engine's placement probe times a plain observation pass into a
-    # set of candidates (up to 32, at most a quarter of the free HBM; ~17 ms once); the two fastest are kept, the rest
-    # go back to torch's allocator.
-    PLACEMENT_CANDIDATES = 32
+    # Placement of the double-buffered observation tensors (reuse_buffers=True).  Physical HBM on MI355X falls into a
+    # few large zones; a store stream confined to one zone sustains ~5.5 TB/s, the same stream with half of its bytes in
+    # another zone ~6.9 TB/s (DESIGN.md "placement", profiles/r2/placement_*.txt).  A plain allocation is physically
+    # compact -- one zone, unless it straddles a boundary by luck (round 1 searched for such lucky buffers by timing up
+    # to 64 candidates).  The engine's buffer pool (pgx_buffers_create) REQUESTS the placement instead: each buffer is
+    # one virtual range whose second half is backed by another zone, verified by timing.  Buffers below 64 MB are
+    # latency-bound and come from torch's allocator as they are.
     PLACEMENT_MIN_BYTES = 64 << 20
 
     def _pick_obs_buffers(self):
         obs_bytes = int(np.prod(self.obs_shape)) * (4 if self.obs_dtype == torch.float32 else 1)
-        batch_n = self.PLACEMENT_CANDIDATES if obs_bytes >= self.PLACEMENT_MIN_BYTES else 2
-        free, _ = torch.cuda.mem_get_info(self.device)
-        budget = max(2, int(free * 0.25) // max(obs_bytes, 1))   # candidates alive at once
-        new = lambda k: [torch.empty(self.obs_shape, dtype=self.obs_dtype, device=self.device) for _ in range(k)]
-        if not self.placement_probe:
-            batch_n = 2
-        if batch_n == 2 or not self._has_state():
-            return new(2)
-        timed = []
-        us = C.c_float()
-        # Fast placements are rare on some devices (1-2 of 32): keep drawing batches while the runner-up is clearly
-        # slower than the best and the memory budget allows; all candidates stay alive meanwhile so that the allocator
-        # cannot hand the same region out twice.
-        while len(timed) < budget:
-            for t in new(min(batch_n, budget - len(timed))):
-                _lib.check(self._lib.pgx_time_observe(self._handle, t.data_ptr(), 3, C.byref(us), self._stream()))
-                timed.append((float(us.value), t))
-            timed.sort(key=lambda x: x[0])
-            if len(timed) >= 2 and timed[1][0] <= 1.03 * timed[0][0]:
-                break
-            if len(timed) >= 3 * batch_n:
-                break
-        self.placement_us = [round(u, 2) for u, _ in timed]
-        return [timed[0][1], timed[1][1]]
+        if not self.placement_probe or obs_bytes < self.PLACEMENT_MIN_BYTES:
+            self.placement = {"spread": False, "method": "torch allocator"}
+            return [torch.empty(self.obs_shape, dtype=self.obs_dtype, device=self.device) for _ in range(2)]
+        from .buffers import ZoneBuffers
+        pool = ZoneBuffers(self.obs_shape, self.obs_dtype, self.device, count=2)
+        self.placement = dict(pool.info, method="pgx_buffers (two HBM zones per buffer)")
+        return pool.tensors
 
     def _has_state(self):
         return self._initial is not None

@@ -61,6 +61,13 @@ def test_lds_limit_is_reported(engine_lib):
     assert "LDS" in engine_lib.pgx_last_error().decode()
 
 
+def test_buffers_info_struct_layout():
+    # struct pgx_buffers_info: int64, 4 x int32, 2 x float, double, 2 x float
+    assert C.sizeof(_lib.PgxBuffersInfo) == 8 + 16 + 8 + 8 + 8
+    assert _lib.PgxBuffersInfo.same_zone_us.offset == 24 and _lib.PgxBuffersInfo.spacer_gib.offset == 32
+    assert _lib.PgxBuffersInfo.buffer_gbs.offset == 40
+
+
 def test_null_arguments(engine_lib):
     assert engine_lib.pgx_step(None, None, 0, None, None, None, None, None, None) == -1
     assert engine_lib.pgx_observe(None, None, None) == -1

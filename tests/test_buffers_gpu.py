@@ -1,0 +1,62 @@
+"""GPU: the zone-aware buffer pool (pgx_buffers_*, pogema_amd/buffers.py) -- one contiguous virtual range per buffer,
+usable like any device memory, and (when another HBM zone is reachable) verified faster for a store stream."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_pool_buffers_are_ordinary_device_memory():
+    import torch
+    from pogema_amd.buffers import ZoneBuffers
+    shape = (1024, 64, 3, 11, 11)  # 95 MB: large enough for the zone search
+    pool = ZoneBuffers(shape, torch.float32, "cuda:0", count=2)
+    a, b = pool.tensors
+    assert a.shape == shape and a.dtype == torch.float32 and a.is_contiguous() and a.data_ptr() != b.data_ptr()
+    assert a.data_ptr() % (2 << 20) == 0
+    ref = torch.arange(a.numel(), dtype=torch.float32, device="cuda").view(shape) % 977
+    a.copy_(ref)            # torch kernels write across the seam between the two physical halves
+    b.fill_(3.0)
+    assert torch.equal(a, ref) and float(b.sum()) == 3.0 * b.numel()
+    assert torch.equal(a.cpu(), ref.cpu())  # D2H copies too
+    info = pool.info
+    assert info["count"] == 2 and info["bytes"] == a.numel() * 4 and info["same_zone_us"] > 0
+    if info["spread"]:
+        assert info["final_us"] < 0.9 * info["same_zone_us"]
+    # the memory outlives the pool object for as long as a tensor references it
+    del pool, b
+    a.add_(1.0)
+    torch.cuda.synchronize()
+    assert torch.equal(a, ref + 1.0)
+
+
+def test_pool_without_search_and_small_sizes():
+    import torch
+    from pogema_amd.buffers import ZoneBuffers
+    pool = ZoneBuffers((3, 5, 7), torch.uint8, "cuda:0", count=3, max_spacer_gib=0)  # < one granule: a single handle
+    assert not pool.info["spread"] and pool.info["candidates"] == 0 and len(pool.tensors) == 3
+    for k, t in enumerate(pool.tensors):
+        t.fill_(k + 1)
+    assert [int(t.sum()) for t in pool.tensors] == [105 * (k + 1) for k in range(3)]
+
+
+def test_engine_parity_on_zone_buffers():
+    """VecPogema(reuse_buffers=True) writes its observations into pool buffers: same results as fresh tensors."""
+    import torch
+    from pogema_amd import GridConfig, VecPogema
+    gc = GridConfig(size=32, num_agents=32, obs_radius=5, density=0.3, seed=3, collision_system="soft")
+    B = 1024  # 1024 x 32 x 1452 B = 47.6 MB per buffer: below the pool threshold -> force it
+    envs = []
+    for reuse in (False, True):
+        env = VecPogema(gc, batch=B, auto_reset=True, reuse_buffers=reuse)
+        env.PLACEMENT_MIN_BYTES = 1 << 20
+        env.reset(seed=3)
+        envs.append(env)
+    acts = torch.randint(0, 5, (6, B, 32), device="cuda", dtype=torch.int8)
+    for t in range(6):
+        o0, r0, te0, tr0, _ = envs[0].step(acts[t])
+        o1, r1, te1, tr1, _ = envs[1].step(acts[t])
+        assert torch.equal(o0, o1) and torch.equal(r0, r1) and torch.equal(te0, te1) and torch.equal(tr0, tr1)
+    assert envs[1].placement["method"].startswith("pgx_buffers")
+    for e in envs:
+        e.close()

@@ -1,5 +1,5 @@
-O=gpurun_out/r2_diag; mkdir -p $O; rm -f $O/ab.txt
-for wl in cfg3 cfg1 cfg2 cfg4; do
-python tools/ab_inproc.py $wl "PGX_FLAGS=0" "PGX_FLAGS=1" "PGX_FLAGS=16" "PGX_FLAGS=32" "PGX_FLAGS=0" 2>&1 | grep -v amdgpu.ids >> $O/ab.txt
-done
-cat $O/ab.txt
+O=gpurun_out/r2_diag; mkdir -p $O; rm -f $O/ab2.txt
+python tools/ab_inproc.py cfg3 "PGX_FLAGS=16" "PGX_FLAGS=16,PGX_LDS_MIN=10000" "PGX_FLAGS=16,PGX_LDS_MIN=20000" "PGX_FLAGS=16,PGX_LDS_MIN=40000" "PGX_FLAGS=16,PGX_EPW=2" "PGX_FLAGS=16,PGX_EPW=2,PGX_LDS_MIN=20000" "PGX_FLAGS=16,PGX_EPW=4" "PGX_FLAGS=16,PGX_EPW=4,PGX_LDS_MIN=40000" "PGX_FLAGS=16" 2>&1 | grep -v amdgpu.ids >> $O/ab2.txt
+python tools/ab_inproc.py cfg1 "PGX_FLAGS=16" "PGX_FLAGS=16,PGX_LDS_MIN=20000" "PGX_FLAGS=16,PGX_LDS_MIN=40000"  "PGX_FLAGS=16,PGX_EPW=2" "PGX_FLAGS=16" 2>&1 | grep -v amdgpu.ids >> $O/ab2.txt
+python tools/ab_inproc.py cfg2 "PGX_FLAGS=16" "PGX_FLAGS=16,PGX_LDS_MIN=10000" "PGX_FLAGS=16,PGX_LDS_MIN=20000" "PGX_FLAGS=16,PGX_STAGGER=0" "PGX_FLAGS=16,PGX_STAGGER=0,PGX_LDS_MIN=10000" "PGX_FLAGS=16" 2>&1 | grep -v amdgpu.ids >> $O/ab2.txt
+cat $O/ab2.txt

@@ -181,6 +181,15 @@ int pgx_get_map(pgx_env* env, uint8_t* obstacles, void* stream);
 int pgx_step(pgx_env* env, const void* actions, int action_dtype, void* obs, float* rewards,
              uint8_t* terminated, uint8_t* truncated, uint8_t* is_active, void* stream);
 
+/* Overwrites the current targets of the agents flagged in `agent_mask` (device u8 [batch, agents]; NULL = all agents).
+ *   target_xy  device i32 [batch, agents, 2]  unpadded (row, col); must be free cells inside the map (not checked)
+ * `PogemaLifeLong` draws new targets from per-agent numpy generators (upstream pogema/envs.py `_generate_new_target`,
+ * pogema/generator.py); the engine's own lifelong stream is a different one (docs/SPEC.md S5).  This call lets a caller
+ * supply the targets instead -- a user-defined task generator, or the recorded target sequence of a reference rollout
+ * (tests/test_golden_reference.py replays lifelong fixtures this way).  The stored initial targets (auto-reset state)
+ * are not touched.  Asynchronous on `stream`. */
+int pgx_set_targets(pgx_env* env, const int32_t* target_xy, const uint8_t* agent_mask, void* stream);
+
 /* Number of out-of-range actions (outside 0..4) that ACTIVE agents submitted since the last call (bad_action =
  * PGX_BAD_ACTION_FLAG only; otherwise always 0).  Inactive agents' actions are never looked at, as in the reference's
  * `if self.grid.is_active[agent_idx]` guards.  Synchronises `stream`, then clears the counter.  The host side turns a
@@ -255,8 +264,10 @@ int pgx_get_state(pgx_env* env, int32_t* agent_xy, int32_t* target_xy, uint8_t* 
  * accumulators, generation counters, lifelong tables and draw counters) as one opaque device blob of
  * pgx_snapshot_bytes() bytes.  Replaces `PersistentWrapper`'s per-step state history / `step_back` (upstream
  * pogema/wrappers/persistence.py) and gives checkpoint-resume: a loaded snapshot continues bit-identically.
- * The blob is only valid for a handle of the same configuration (checked: ABI version, batch, agents).
- * Both calls synchronise `stream` once for the 16-byte header; the payload copies are asynchronous. */
+ * The blob is only valid for a handle of the same configuration; the 64-byte header records ABI version, batch,
+ * agents, map height/width, obs_radius, on_target, collision_system, max_episode_steps and the total byte count, and
+ * pgx_load_snapshot refuses (PGX_E_INVALID) a blob whose header differs from the loading handle's in any of them.
+ * Both calls synchronise `stream` once for the header; the payload copies are asynchronous. */
 int64_t pgx_snapshot_bytes(pgx_env* env);
 int pgx_save_snapshot(pgx_env* env, void* blob, void* stream);
 int pgx_load_snapshot(pgx_env* env, const void* blob, void* stream);

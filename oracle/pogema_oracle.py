@@ -471,6 +471,14 @@ class PogemaOracle:
         tx, ty = comp[k]
         return (tx + r, ty + r)
 
+    def set_targets(self, targets_xy, mask=None):
+        """Overwrite the current targets (unpadded coordinates) of the agents flagged in `mask` (None = all): replay
+        of a recorded lifelong target sequence (tests/test_golden_reference.py)."""
+        r = self.obs_radius
+        for i, (x, y) in enumerate(targets_xy):
+            if mask is None or mask[i]:
+                self.grid.finishes_xy[i] = (int(x) + r, int(y) + r)
+
     # -- state export (unpadded coordinates), used by parity tests ---------------------------------
     def get_state(self):
         g = self.grid

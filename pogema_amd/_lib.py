@@ -49,7 +49,7 @@ EXPORTED_SYMBOLS = (
     "pgx_abi_version", "pgx_last_error", "pgx_create", "pgx_destroy", "pgx_obs_elems", "pgx_agent_elems",
     "pgx_reset_from_state", "pgx_reset_random", "pgx_regenerate", "pgx_regenerate_failures", "pgx_get_map", "pgx_step", "pgx_observe", "pgx_set_metrics_buffers", "pgx_get_state", "pgx_generate", "pgx_place_agents",
     "pgx_snapshot_bytes", "pgx_save_snapshot", "pgx_load_snapshot", "pgx_time_observe", "pgx_bad_action_count",
-    "pgx_buffers_create", "pgx_buffers_ptr", "pgx_buffers_get_info", "pgx_buffers_destroy",
+    "pgx_buffers_create", "pgx_buffers_ptr", "pgx_buffers_get_info", "pgx_buffers_destroy", "pgx_set_targets",
 )
 
 
@@ -119,6 +119,8 @@ def load() -> C.CDLL:
     lib.pgx_buffers_get_info.restype = C.c_int
     lib.pgx_buffers_destroy.argtypes = [vp]
     lib.pgx_buffers_destroy.restype = C.c_int
+    lib.pgx_set_targets.argtypes = [vp, vp, vp, vp]
+    lib.pgx_set_targets.restype = C.c_int
     lib.pgx_bad_action_count.argtypes = [vp, vp]
     lib.pgx_bad_action_count.restype = i64
     lib.pgx_time_observe.argtypes = [vp, vp, i32, C.POINTER(C.c_float), vp]

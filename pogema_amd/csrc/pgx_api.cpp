@@ -161,6 +161,10 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
     e->geo = pgx::step_geometry(cfg->batch, A, e->bmw, e->W, !(e->flags & 2u), epw_override,
                                 cfg->obs_dtype == PGX_OBS_U8 ? 1 : 4, waves_override);
     if (const char* f = getenv("PGX_STAGGER")) e->geo.stagger = atoi(f);  // tuning/diagnostic override
+    if (const char* f = getenv("PGX_STORE")) {  // tuning/diagnostic override: plain | nt | sc1
+        const std::string v = f;
+        e->geo.store_policy = v == "plain" ? 0 : v == "nt" ? 1 : v == "sc1" ? 2 : e->geo.store_policy;
+    }
     if (const char* f = getenv("PGX_LDS_MIN")) {  // diagnostic: cap residency by reserving LDS per workgroup
         const size_t m = (size_t)atol(f);
         if (m > e->geo.lds_bytes) e->geo.lds_bytes = (m + 15) & ~(size_t)15;
@@ -277,9 +281,19 @@ static int ensure_reset_scratch(pgx_env* e, bool full) {
         e->labels = e->pending = nullptr;
         e->scratch_map = nullptr;
     }
-    PGX_HIP(hipMalloc((void**)&e->labels, chunk * cells * sizeof(uint32_t)));
-    PGX_HIP(hipMalloc((void**)&e->pending, chunk * cells * sizeof(uint32_t)));
-    PGX_HIP(hipMalloc((void**)&e->scratch_map, chunk * cells));
+    e->chunk_envs = 0;
+    hipError_t err = hipMalloc((void**)&e->labels, chunk * cells * sizeof(uint32_t));
+    if (err == hipSuccess) err = hipMalloc((void**)&e->pending, chunk * cells * sizeof(uint32_t));
+    if (err == hipSuccess) err = hipMalloc((void**)&e->scratch_map, chunk * cells);
+    if (err != hipSuccess) {  // all or nothing: a later call must not find half of the scratch
+        if (e->labels) (void)hipFree(e->labels);
+        if (e->pending) (void)hipFree(e->pending);
+        if (e->scratch_map) (void)hipFree(e->scratch_map);
+        e->labels = e->pending = nullptr;
+        e->scratch_map = nullptr;
+        return fail(err == hipErrorOutOfMemory ? PGX_E_NOMEM : PGX_E_HIP, "reset scratch (%zu bytes): %s", chunk * cells * 9,
+                    hipGetErrorString(err));
+    }
     e->chunk_envs = (int)chunk;
     return PGX_OK;
 }
@@ -450,12 +464,29 @@ std::vector<Segment> snapshot_segments(pgx_env* e) {
     return seg;
 }
 size_t aligned16(size_t n) { return (n + 15) & ~(size_t)15; }
+// Snapshot header: everything the segment sizes and the meaning of the payload depend on.
+constexpr int32_t SNAP_MAGIC = 0x50475853;  // 'PGXS'
+constexpr size_t SNAP_HEADER_BYTES = 64;
+struct SnapHeader {
+    int32_t magic, abi, batch, num_agents, height, width, obs_radius, on_target, collision_system, max_episode_steps;
+    int64_t total_bytes;
+    int32_t pad[4];
+};
+static_assert(sizeof(SnapHeader) == SNAP_HEADER_BYTES, "snapshot header layout");
+SnapHeader snapshot_header(pgx_env* e, int64_t total) {
+    const pgx_config& c = e->cfg;
+    SnapHeader h{};
+    h.magic = SNAP_MAGIC; h.abi = PGX_ABI_VERSION; h.batch = c.batch; h.num_agents = c.num_agents;
+    h.height = c.height; h.width = c.width; h.obs_radius = c.obs_radius; h.on_target = c.on_target;
+    h.collision_system = c.collision_system; h.max_episode_steps = c.max_episode_steps; h.total_bytes = total;
+    return h;
+}
 }  // namespace
 }  // extern "C++"
 
 int64_t pgx_snapshot_bytes(pgx_env* e) {
     if (!e) return 0;
-    size_t total = 16;  // header: magic, abi version, batch, agents
+    size_t total = SNAP_HEADER_BYTES;
     for (const Segment& s : snapshot_segments(e)) total += aligned16(s.bytes);
     return (int64_t)total;
 }
@@ -466,10 +497,10 @@ int pgx_save_snapshot(pgx_env* e, void* blob, void* stream) {
     DeviceGuard guard(e->device);
     if (guard.err != hipSuccess) return fail(PGX_E_HIP, "cannot select device: %s", hipGetErrorString(guard.err));
     hipStream_t s = (hipStream_t)stream;
-    const int32_t header[4] = {0x50475853 /* 'PGXS' */, PGX_ABI_VERSION, e->cfg.batch, e->cfg.num_agents};
-    PGX_HIP(hipMemcpyAsync(blob, header, sizeof header, hipMemcpyHostToDevice, s));
+    const SnapHeader header = snapshot_header(e, pgx_snapshot_bytes(e));
+    PGX_HIP(hipMemcpyAsync(blob, &header, sizeof header, hipMemcpyHostToDevice, s));
     PGX_HIP(hipStreamSynchronize(s));  // `header` lives on this stack frame
-    size_t off = 16;
+    size_t off = SNAP_HEADER_BYTES;
     for (const Segment& g : snapshot_segments(e)) {
         PGX_HIP(hipMemcpyAsync((char*)blob + off, g.ptr, g.bytes, hipMemcpyDeviceToDevice, s));
         off += aligned16(g.bytes);
@@ -482,14 +513,20 @@ int pgx_load_snapshot(pgx_env* e, const void* blob, void* stream) {
     DeviceGuard guard(e->device);
     if (guard.err != hipSuccess) return fail(PGX_E_HIP, "cannot select device: %s", hipGetErrorString(guard.err));
     hipStream_t s = (hipStream_t)stream;
-    int32_t header[4] = {0, 0, 0, 0};
-    PGX_HIP(hipMemcpyAsync(header, blob, sizeof header, hipMemcpyDeviceToHost, s));
+    SnapHeader got{};
+    PGX_HIP(hipMemcpyAsync(&got, blob, sizeof got, hipMemcpyDeviceToHost, s));
     PGX_HIP(hipStreamSynchronize(s));
-    if (header[0] != 0x50475853 || header[1] != PGX_ABI_VERSION || header[2] != e->cfg.batch ||
-        header[3] != e->cfg.num_agents)
-        return fail(PGX_E_INVALID, "snapshot does not belong to this configuration (magic %08x, abi %d, batch %d, agents %d)",
-                    (unsigned)header[0], header[1], header[2], header[3]);
-    size_t off = 16;
+    const SnapHeader want = snapshot_header(e, pgx_snapshot_bytes(e));
+    if (memcmp(&got, &want, sizeof want) != 0)
+        return fail(PGX_E_INVALID,
+                    "snapshot does not belong to this configuration: blob has magic %08x abi %d batch %d agents %d map %dx%d "
+                    "r %d on_target %d collision %d max_steps %d bytes %lld; this handle abi %d batch %d agents %d map %dx%d "
+                    "r %d on_target %d collision %d max_steps %d bytes %lld",
+                    (unsigned)got.magic, got.abi, got.batch, got.num_agents, got.height, got.width, got.obs_radius,
+                    got.on_target, got.collision_system, got.max_episode_steps, (long long)got.total_bytes, want.abi,
+                    want.batch, want.num_agents, want.height, want.width, want.obs_radius, want.on_target,
+                    want.collision_system, want.max_episode_steps, (long long)want.total_bytes);
+    size_t off = SNAP_HEADER_BYTES;
     for (const Segment& g : snapshot_segments(e)) {
         PGX_HIP(hipMemcpyAsync(g.ptr, (const char*)blob + off, g.bytes, hipMemcpyDeviceToDevice, s));
         off += aligned16(g.bytes);
@@ -526,6 +563,7 @@ static void fill_params(const pgx_env* e, pgx::StepParams& p) {
     p.flags = e->flags;
     p.epw = e->geo.epw;
     p.stagger = e->geo.stagger;
+    p.store_policy = e->geo.store_policy;
     p.obs_u8 = e->cfg.obs_dtype == PGX_OBS_U8 ? 1 : 0;
     p.soft_rule = c.soft_vertex_rule;
     p.coop_reward = c.coop_reward;
@@ -568,6 +606,16 @@ int pgx_step(pgx_env* e, const void* actions, int action_dtype, void* obs, float
     p.truncated = truncated;
     p.act_out = is_active;
     PGX_HIP(pgx::launch_step(p, e->geo, (hipStream_t)stream));
+    return PGX_OK;
+}
+
+int pgx_set_targets(pgx_env* e, const int32_t* target_xy, const uint8_t* agent_mask, void* stream) {
+    if (!e || !target_xy) return fail(PGX_E_INVALID, "pgx_set_targets: null argument");
+    if (!e->has_state) return fail(PGX_E_STATE, "pgx_set_targets called before a reset");
+    DeviceGuard guard(e->device);
+    if (guard.err != hipSuccess) return fail(PGX_E_HIP, "cannot select device: %s", hipGetErrorString(guard.err));
+    PGX_HIP(pgx::launch_set_targets(target_xy, agent_mask, e->tgt, (size_t)e->cfg.batch * e->cfg.num_agents,
+                                    e->cfg.obs_radius, (hipStream_t)stream));
     return PGX_OK;
 }
 

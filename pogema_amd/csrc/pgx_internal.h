@@ -61,10 +61,11 @@ struct StepParams {
     int32_t epw;       // environments per wave (single-wave blocks, num_agents <= 64)
     int32_t obs_u8;    // 1: `obs` is uint8 (one byte per cell) instead of float32
     int32_t stagger;   // cohort stagger of the single-wave kernel (StepGeometry::stagger)
+    int32_t store_policy;  // observation stores: 0 plain, 1 nontemporal, 2 sc1 write-through (StepGeometry::store_policy)
     int32_t soft_rule;    // PGX_SOFT_*  (docs/SPEC.md Q1)
     int32_t coop_reward;  // PGX_COOP_REWARD_* (Q4)
     int32_t bad_action;   // PGX_BAD_ACTION_* (Q7)
-    uint32_t flags;    // tuning switches (PGX_FLAGS env var at pgx_create): bit0 = nontemporal obs stores
+    uint32_t flags;    // diagnostic switches (PGX_FLAGS env var at pgx_create): bit1 generic row path, bit2 time stamps, bit3 identity block mapping
     uint64_t seed;
     int64_t env_index_base;
     // SoA state in HBM
@@ -104,6 +105,7 @@ struct StepGeometry {
     bool multi_wave;  // num_agents > 64: one environment per workgroup
     bool p16;         // window side <= 16: packed 16-bit row masks aliased over the LDS state
     int stagger;      // > 0: odd wave slots sleep this many x 8128 cycles after issuing their loads
+    int store_policy; // observation store flavour (pgx_kernels.hip: store_obs16)
     size_t lds_bytes;
 };
 StepGeometry step_geometry(int batch, int A, int bmw, int W, bool allow_p16, int epw_override, int obs_elem_bytes,
@@ -151,6 +153,8 @@ hipError_t launch_pack_agents(const int32_t* agent_xy, const int32_t* target_xy,
                               uint32_t* pos0, uint32_t* tgt0, uint8_t* active, uint32_t* tcount, size_t n,
                               int r, hipStream_t stream);
 hipError_t launch_zero_i32(int32_t* v, size_t n, hipStream_t stream);
+hipError_t launch_set_targets(const int32_t* target_xy, const uint8_t* mask, uint32_t* tgt, size_t n, int r,
+                              hipStream_t stream);
 hipError_t launch_unpack_state(const uint32_t* pos, const uint32_t* tgt, const uint8_t* active, int32_t* agent_xy,
                                int32_t* target_xy, uint8_t* act_out, size_t n, int r, hipStream_t stream);
 hipError_t launch_occupancy(const uint32_t* pos, const uint8_t* active, uint8_t* occ, size_t n, int A, int PH,

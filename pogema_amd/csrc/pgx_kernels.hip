@@ -20,6 +20,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "pgx_internal.h"
 
 namespace pgx {
@@ -111,10 +115,31 @@ __device__ __forceinline__ void pair_min(uint32_t pj, uint32_t qj, uint32_t wsh,
 
 // One slot of G partners whose (P, Q) words sit in the lanes of this wave's group: G-1 DPP rotations (plus the
 // unrotated words when the slot belongs to another wave, `with_k0`).
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
+}
+
 template <int G>
 __device__ __forceinline__ void sweep_slot(uint32_t pj, uint32_t qj, bool with_k0, int src, uint32_t wsh, uint32_t im1,
                                            SweepAcc& a) {
     if (with_k0) pair_min(pj, qj, wsh, im1, a);
+    if constexpr (G == 8) {
+        // No 8-lane rotation exists in DPP, but the seven partners of lane i are exactly i ^ 1 .. i ^ 7 and the order of
+        // the visits does not matter (three running minima): i^1, i^2, i^3 are quad permutations, i^7 is
+        // row_half_mirror, i^6 / i^5 / i^4 are quad permutations of the mirrored words.  14 independent DPP moves
+        // instead of a dependent chain of 14 ds_bpermute round trips (configs[1]: -0.5 us on the step's critical path).
+        constexpr int X1 = 0xB1, X2 = 0x4E, X3 = 0x1B, HM = 0x141;  // quad_perm [1,0,3,2] / [2,3,0,1] / [3,2,1,0], row_half_mirror
+        const uint32_t ph = dpp<HM>(pj), qh = dpp<HM>(qj);
+        pair_min(dpp<X1>(pj), dpp<X1>(qj), wsh, im1, a);
+        pair_min(dpp<X2>(pj), dpp<X2>(qj), wsh, im1, a);
+        pair_min(dpp<X3>(pj), dpp<X3>(qj), wsh, im1, a);
+        pair_min(ph, qh, wsh, im1, a);
+        pair_min(dpp<X1>(ph), dpp<X1>(qh), wsh, im1, a);
+        pair_min(dpp<X2>(ph), dpp<X2>(qh), wsh, im1, a);
+        pair_min(dpp<X3>(ph), dpp<X3>(qh), wsh, im1, a);
+        return;
+    }
     for (int k = 1; k < G; ++k) {
         pj = rot1<G>(pj, src);
         qj = rot1<G>(qj, src);
@@ -141,14 +166,16 @@ __device__ __forceinline__ void lds_sync() {
 }
 
 
-// 16-byte observation store.  policy 0: plain (line stays in the XCD's L2), 1: nontemporal, 2: sc1 (write-through, the
-// line is dropped from L2 -- the observation stream then does not evict the small per-step state from the L2s).
+// 16-byte observation store (StepParams::store_policy).  0: plain (the line stays in the XCD's L2), 1: nontemporal,
+// 2: sc1 (write-through: the line leaves the L2 at once, so the stream neither evicts the small per-step state from the
+// L2s nor leaves megabytes of dirty lines to be flushed at the kernel boundary).  Measured, same buffers (ab_inproc):
+// sc1 vs plain -1.3 % configs[2], -3.6 % configs[3], -10 % configs[1]; the multi-wave kernel (configs[4]) prefers
+// nontemporal (-1 %), sc1 costs it +0.5 %.  step_geometry() picks; PGX_STORE overrides.
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_obs16(f32x4_t* ptr, f32x4_t v, uint32_t policy) {
     if (policy == 0u) *ptr = v;
     else if (policy == 1u) __builtin_nontemporal_store(v, ptr);
-    else if (policy == 2u) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory");
-    else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(ptr), "v"(v) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory");
 }
 
 // uint8 observation stream (obs_dtype = PGX_OBS_U8; NOT the drop-in dtype -- a 4x lighter mode for callers that
@@ -594,7 +621,7 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
         if (p.obs_u8) {
             if (dbg && !dbg2 && tid == 0) p.dbg[(size_t)blk * 4 + 2] = wall_clock64();
             const int nrows = nag * 3 * W;
-            stream_obs_u8(reinterpret_cast<uint8_t*>(p.obs), base, n, W, p.w_magic, tid, NT, (p.flags & 1u) != 0,
+            stream_obs_u8(reinterpret_cast<uint8_t*>(p.obs), base, n, W, p.w_magic, tid, NT, p.store_policy == 1,
                           [&](int row) -> uint32_t { return row < nrows ? (uint32_t)rows16[row] : 0u; });
             if (dbg && !dbg2 && tid == 0) {
                 __builtin_amdgcn_s_waitcnt(0);
@@ -619,7 +646,7 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
         if (dbg && !dbg2 && tid == 0) p.dbg[(size_t)blk * 4 + 2] = wall_clock64();
         typedef float f32x4 __attribute__((ext_vector_type(4)));
         f32x4* out4 = reinterpret_cast<f32x4*>(out + head);
-        const uint32_t spol = (p.flags & 1u) | ((p.flags >> 3) & 2u) | ((p.flags & 32u) ? 3u : 0u);
+        const uint32_t spol = (uint32_t)p.store_policy;
         const uint32_t* rows32 = smem;
         // flat float offset e0 = head + 4q advances by 4*NT per iteration: keep (row, col) incrementally
         int e0 = head + (tid << 2);
@@ -689,7 +716,7 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
     if (p.obs_u8) {
         const int nrows = nag * 3 * W;
         stream_obs_u8(reinterpret_cast<uint8_t*>(p.obs), (size_t)env0 * A * 3 * W * W, nrows * W, W, p.w_magic, tid, NT,
-                      (p.flags & 1u) != 0, [&](int row) -> uint32_t { return row < nrows ? s_rows[row] : 0u; });
+                      p.store_policy == 1, [&](int row) -> uint32_t { return row < nrows ? s_rows[row] : 0u; });
         return;
     }
     {
@@ -723,8 +750,7 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
             v.y = (float)((b >> 1) & 1u);
             v.z = (float)((b >> 2) & 1u);
             v.w = (float)((b >> 3) & 1u);
-            if (p.flags & 1u) __builtin_nontemporal_store(v, &out4[q]);
-            else out4[q] = v;
+            store_obs16(reinterpret_cast<f32x4_t*>(&out4[q]), v, (uint32_t)p.store_policy);
         }
         if (dbg && !dbg2 && tid == 0) {
             __builtin_amdgcn_s_waitcnt(0);  // stores retired (vmcnt 0) before the end stamp
@@ -786,6 +812,14 @@ __global__ void pack_agents_kernel(const int32_t* __restrict__ agent_xy, const i
     tgt0[i] = tc;
     active[i] = 1;
     if (tcount) tcount[i] = 0u;
+}
+
+// pgx_set_targets: overwrite the targets of the flagged agents (all when mask == null)
+__global__ void set_targets_kernel(const int32_t* __restrict__ target_xy, const uint8_t* __restrict__ mask,
+                                   uint32_t* __restrict__ tgt, size_t n, int r) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || (mask && !mask[i])) return;
+    tgt[i] = ((uint32_t)(target_xy[2 * i] + r) << 16) | (uint32_t)(target_xy[2 * i + 1] + r);
 }
 
 __global__ void zero_i32_kernel(int32_t* v, size_t n) {
@@ -879,6 +913,7 @@ StepGeometry step_geometry(int batch, int A, int bmw, int W, bool allow_p16, int
         if (epw_override > 0) g.epw = epw_override < max_epw ? epw_override : max_epw;
     }
     g.p16 = allow_p16 && W <= 16;
+    g.store_policy = g.multi_wave ? 1 : 2;  // see store_obs16()
     // Cohort stagger (step_kernel phase 1): pays when every wave of the launch is resident at once (one round of at
     // most 256 CUs x 32 waves, at least half of them used) and each wave streams for long (>= 32 KB of observations):
     // -2.3 % per configs[2] step in a buffer-controlled A/B on two boxes (profiles/r1/controlled_ab.txt); with several
@@ -905,13 +940,24 @@ StepGeometry step_geometry(int batch, int A, int bmw, int W, bool allow_p16, int
     return g;
 }
 
-// once per handle (NOT per launch: keeps pgx_step capturable in a HIP graph)
+// once per handle (NOT per launch: keeps pgx_step capturable in a HIP graph).  The > 48 KB opt-in is an attribute of
+// the kernel FUNCTION on a device, not of a handle: two live handles may share a template instance with different LDS
+// needs, so the limit is only ever raised (largest request so far per function and device).
 hipError_t prepare_step(const StepGeometry& g) {
     const void* fn = step_fn_for(g);
     if (!fn) return hipErrorInvalidValue;
-    if (g.lds_bytes > 48 * 1024)
-        return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
-    return hipSuccess;
+    if (g.lds_bytes <= 48 * 1024) return hipSuccess;
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, size_t> granted;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& have = granted[{fn, dev}];
+    if (g.lds_bytes <= have) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+    if (e == hipSuccess) have = g.lds_bytes;
+    return e;
 }
 
 hipError_t launch_step(const StepParams& p, const StepGeometry& g, hipStream_t stream) {
@@ -938,6 +984,13 @@ hipError_t launch_pack_agents(const int32_t* agent_xy, const int32_t* target_xy,
     const int bs = 256;
     hipLaunchKernelGGL(pack_agents_kernel, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, stream, agent_xy,
                        target_xy, pos, tgt, pos0, tgt0, active, tcount, n, r);
+    return hipGetLastError();
+}
+
+hipError_t launch_set_targets(const int32_t* target_xy, const uint8_t* mask, uint32_t* tgt, size_t n, int r,
+                              hipStream_t stream) {
+    const int bs = 256;
+    hipLaunchKernelGGL(set_targets_kernel, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, stream, target_xy, mask, tgt, n, r);
     return hipGetLastError();
 }
 

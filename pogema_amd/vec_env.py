@@ -413,6 +413,25 @@ class VecPogema:
         infos = {"is_active": is_active, "episode_done": self.episode_done, "metrics": self.metrics}
         return (self._wrap_obs(obs) if compute_obs else None), rewards, terminated, truncated, infos
 
+    def set_targets(self, targets_xy, mask=None):
+        """Overwrite current targets (int [batch, agents, 2], unpadded (row, col)) of the agents flagged in `mask`
+        (bool/uint8 [batch, agents]; None = all): a caller-supplied task generator in place of the engine's lifelong
+        stream, or the recorded targets of a reference rollout.  Cells must be free and inside the map."""
+        t = torch.as_tensor(np.asarray(targets_xy) if not isinstance(targets_xy, torch.Tensor) else targets_xy)
+        t = t.to(self.device).to(torch.int32).contiguous()
+        if tuple(t.shape) != (self.batch, self.num_agents, 2):
+            raise ValueError(f"targets_xy must have shape {(self.batch, self.num_agents, 2)}")
+        if bool(((t[..., 0] < 0) | (t[..., 0] >= self.height) | (t[..., 1] < 0) | (t[..., 1] >= self.width)).any()):
+            raise IndexError(f"targets_xy outside the {self.height}x{self.width} map")
+        m = None
+        if mask is not None:
+            m = torch.as_tensor(np.asarray(mask) if not isinstance(mask, torch.Tensor) else mask)
+            m = m.to(self.device).to(torch.uint8).contiguous()
+            if m.numel() != self.batch * self.num_agents:
+                raise ValueError("mask must have batch x agents entries")
+        _lib.check(self._lib.pgx_set_targets(self._handle, t.data_ptr(), m.data_ptr() if m is not None else None,
+                                             self._stream()))
+
     def _wrap_obs(self, obs: torch.Tensor):
         """'default': the float32 tensor.  'POMAPF' / 'MAPF' (upstream `PogemaBase._pomapf_obs` / `_mapf_obs`):
         dict views over the same planes plus coordinates relative to each agent's start cell (and, for MAPF,
@@ -442,6 +461,7 @@ class VecPogema:
         blob = state["engine"].to(self.device).contiguous()
         if blob.numel() != int(self._lib.pgx_snapshot_bytes(self._handle)):
             raise ValueError("snapshot size does not match this environment's configuration")
+        # (the engine compares the blob's header -- geometry, modes, byte count -- with this handle's and refuses a mismatch)
         _lib.check(self._lib.pgx_load_snapshot(self._handle, blob.data_ptr(), self._stream()))
         self._initial = None if state["initial"] is None else tuple(t.to(self.device).clone() for t in state["initial"])
         self._reset_seed = state["reset_seed"]

@@ -269,3 +269,101 @@ def test_text_render():
     env.step([2, 0])  # agent a moves down
     assert env.render() == "..#\na.B\nbA."
     env.close()
+
+
+def test_snapshot_refuses_a_different_configuration():
+    """The snapshot header records the geometry and the modes: a blob of the SAME byte size but another configuration
+    (H x W swapped; another collision system; another time limit) is refused instead of installing garbage."""
+    from pogema_amd import GridConfig, VecPogema
+    from pogema_amd._lib import PgxError
+    base = dict(num_agents=3, obs_radius=2, seed=1, max_episode_steps=9, collision_system="soft")
+    tall = [[0] * 6 for _ in range(10)]
+    wide = [[0] * 10 for _ in range(6)]
+    a = VecPogema(GridConfig(map=tall, **base), batch=4)
+    a.reset(seed=1)
+    snap = a.save_state()
+    for other_gc in (GridConfig(map=wide, **base), GridConfig(map=tall, **{**base, "collision_system": "priority"}),
+                     GridConfig(map=tall, **{**base, "max_episode_steps": 10})):
+        b = VecPogema(other_gc, batch=4)
+        b.reset(seed=1)
+        with pytest.raises((PgxError, ValueError), match="configuration"):
+            b.load_state(snap)
+        b.close()
+    same = VecPogema(GridConfig(map=tall, **base), batch=4)
+    same.load_state(snap)  # the matching configuration still loads
+    same.close()
+    a.close()
+
+
+def test_reset_validates_user_supplied_cells():
+    """a GridConfig with explicit `map` + `agents_xy`/`targets_xy` must be validated: an obstacle under a
+    start or target is freed with a warning (upstream Grid.__init__, as recalled), two agents on one start cell raise."""
+    import warnings
+    from pogema_amd import GridConfig, VecPogema
+    grid = "..#.\n....\n.#..\n...."
+    env = VecPogema(GridConfig(map=grid, agents_xy=[[0, 2], [1, 1]], targets_xy=[[2, 1], [3, 3]], obs_radius=2), batch=3)
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        obs, _ = env.reset()
+    assert any("obstacle" in str(w.message) for w in seen)
+    maps = env._initial[0].cpu().numpy()
+    assert maps[:, 0, 2].sum() == 0 and maps[:, 2, 1].sum() == 0, "the cells under the start and the target were freed"
+    st = env.get_state()
+    assert st["agents_xy"][0].tolist() == [[0, 2], [1, 1]]
+    assert float(obs[0, 0, 0, 2, 2]) == 0.0, "agent 0 does not stand inside a wall in its own observation"
+    env.close()
+    dup = VecPogema(GridConfig(map=grid, agents_xy=[[1, 1], [1, 1]], targets_xy=[[0, 0], [3, 3]], obs_radius=2), batch=2)
+    with pytest.raises(KeyError, match="share a start"):
+        dup.reset()
+    dup.close()
+    # the low-level entry keeps raising by default
+    raw = VecPogema(GridConfig(map=grid, num_agents=2, obs_radius=2), batch=1)
+    with pytest.raises(KeyError, match="obstacle"):
+        raw.reset_from_state(np.array([[0, 0, 1, 0], [0, 0, 0, 0], [0, 1, 0, 0], [0, 0, 0, 0]], np.uint8),
+                             np.array([[0, 2], [1, 1]]), np.array([[3, 0], [3, 3]]))
+    raw.close()
+
+
+def test_step_out_buffers_and_seed_resolved_once():
+    """step(out=...) writes the caller's tensors; reset(seed=None) with GridConfig.seed=None stores the seed that was
+    actually used (_resolve_seed used to be called twice)."""
+    import torch
+    from pogema_amd import GridConfig, VecPogema
+    gc = GridConfig(size=10, num_agents=5, obs_radius=2, density=0.2, seed=None)
+    env = VecPogema(gc, batch=6)
+    env.reset()
+    used = env._reset_seed
+    host = env.generate(seed=used)
+    assert np.array_equal(env._initial[0].cpu().numpy(), host[0]), "generate(reset_seed) reproduces the device instances"
+    acts = torch.randint(0, 5, (6, 5), device="cuda")
+    twin = VecPogema(gc, batch=6)
+    twin.reset(seed=used)
+    out = (torch.empty(env.obs_shape, device="cuda"), torch.empty((6, 5), device="cuda"),
+           torch.empty((6, 5), dtype=torch.bool, device="cuda"), torch.empty((6, 5), dtype=torch.uint8, device="cuda"),
+           torch.empty((6, 5), dtype=torch.bool, device="cuda"))
+    o, r, te, tr, infos = env.step(acts, out=out)
+    assert o.data_ptr() == out[0].data_ptr() and r.data_ptr() == out[1].data_ptr() and infos["is_active"].data_ptr() == out[4].data_ptr()
+    o2, r2, te2, tr2, _ = twin.step(acts)
+    assert torch.equal(o, o2) and torch.equal(r, r2) and torch.equal(te, te2) and torch.equal(tr.bool(), tr2)
+    with pytest.raises(ValueError):
+        env.step(acts, out=(out[0][:3],) + out[1:])
+    env.close()
+    twin.close()
+
+
+def test_two_handles_share_a_kernel_with_different_lds_needs():
+    """the > 48 KB LDS opt-in is per kernel function, not per handle -- a later, smaller handle must not lower
+    it under an earlier, larger one (both run step_kernel<64, true, true>)."""
+    import torch
+    from pogema_amd import GridConfig, VecPogema
+    big = VecPogema(GridConfig(size=460, num_agents=70, obs_radius=3, density=0.05, seed=1), batch=2)   # ~117 KB of LDS
+    big.reset(seed=1)
+    small = VecPogema(GridConfig(size=330, num_agents=70, obs_radius=3, density=0.05, seed=1), batch=2)  # ~62 KB
+    small.reset(seed=1)
+    a = torch.randint(0, 5, (2, 70), device="cuda")
+    for _ in range(3):
+        big.step(a)
+        small.step(a)
+    torch.cuda.synchronize()
+    big.close()
+    small.close()

@@ -1,0 +1,93 @@
+"""The pinning pipeline, end to end, BEFORE the real package exists here: tools/gen_golden.py runs against a stand-in
+`pogema` module built from the oracle (tests/standin_pogema), writes reference_*.npz into a TEMPORARY directory, and the
+loader / comparison of tests/test_golden_reference.py is run on the result -- early termination, `elapsed`, `is_active`
+and the lifelong special case included.  Nothing here says anything about parity with upstream (the stand-in IS the
+oracle); it proves that the one-step pinning procedure of INTEGRATION.md section 5 works."""
+import glob
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import test_golden_reference as tgr
+from util import assert_rollouts_equal, engine_rollout, oracle_rollout
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STANDIN = os.path.join(ROOT, "tests", "standin_pogema")
+
+
+def _generate(out_dir, limit):
+    env = dict(os.environ, PYTHONPATH=STANDIN + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    return subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_golden.py"), "--out", str(out_dir),
+                           "--limit", str(limit)], capture_output=True, text=True, env=env, timeout=900)
+
+
+@pytest.fixture(scope="module")
+def fixtures(tmp_path_factory):
+    out = tmp_path_factory.mktemp("golden_standin")
+    p = _generate(out, 27)  # geometry 0 (BASELINE configs[0]) x 3 collision systems x 3 on_target x 3 seeds
+    assert p.returncode == 0, p.stderr
+    files = sorted(glob.glob(os.path.join(str(out), "reference_*.npz")))
+    assert len(files) == 27 and "wrote 27 fixtures" in p.stdout
+    return files
+
+
+def test_generator_refuses_to_write_standin_output_into_tests_golden():
+    p = _generate(os.path.join(ROOT, "tests", "golden"), 1)
+    assert p.returncode != 0 and "STAND-IN" in p.stderr
+    assert not glob.glob(os.path.join(ROOT, "tests", "golden", "reference_*.npz"))
+
+
+def test_fixture_format_and_early_termination(fixtures):
+    seen_short = False
+    for path in fixtures:
+        z = np.load(path, allow_pickle=False)
+        T, A = z["actions"].shape
+        assert z["obs"].shape[:2] == (T, A) and z["agents_xy"].shape == (T, A, 2) and z["obs0"].shape[0] == A
+        assert z["obstacles"].ndim == 2 and z["agents_xy0"].shape == (A, 2)
+        done = z["terminated"][-1].all() or z["truncated"][-1].all()
+        assert done, "every recorded episode runs to its end"
+        seen_short = seen_short or T < int(z["max_episode_steps"])
+    assert seen_short, "at least one episode must end before the time limit (exercises the action-stream truncation)"
+
+
+def test_oracle_passes_the_loaded_fixtures(fixtures):
+    """Includes the lifelong cases: the stand-in's target stream is seeded differently from the rollout under test
+    (as the real package's numpy stream will be), so the target replay of compare_with_fixture is what makes them pass."""
+    lifelong_with_goals = 0
+    for path in fixtures:
+        tgr.compare_with_fixture(oracle_rollout, path)
+        z = np.load(path, allow_pickle=False)
+        lifelong_with_goals += str(z["on_target"]) == "restart" and float(z["rewards"].sum()) > 0
+    assert lifelong_with_goals >= 2, "the replay path must actually be exercised (lifelong fixtures with goals reached)"
+
+
+def test_lifelong_replay_is_needed(fixtures):
+    """Without the replay a lifelong fixture with a different target stream must NOT match (the replay has teeth)."""
+    for path in fixtures:
+        z = np.load(path, allow_pickle=False)
+        if str(z["on_target"]) != "restart" or float(z["rewards"][:-1].sum()) == 0 or "_s0" in path:
+            continue
+        obstacles, agents, targets, actions, ref, kw = tgr._load(path)
+        got = oracle_rollout(obstacles, agents, targets, actions, **kw)
+        assert not np.array_equal(got["targets_xy"], ref["targets_xy"])
+        return
+    pytest.skip("no lifelong fixture with an early goal among the generated ones")
+
+
+def test_comparison_detects_a_wrong_fixture(fixtures, tmp_path):
+    """A fixture whose expected positions are off by one step must FAIL the comparison (the check has teeth)."""
+    z = dict(np.load(fixtures[0], allow_pickle=False))
+    z["agents_xy"] = np.roll(z["agents_xy"], 1, axis=0)
+    bad = tmp_path / "reference_bad.npz"
+    np.savez_compressed(bad, **z)
+    with pytest.raises(AssertionError):
+        tgr.compare_with_fixture(oracle_rollout, str(bad))
+
+
+@pytest.mark.gpu
+def test_engine_passes_the_loaded_fixtures(fixtures):
+    for path in fixtures:
+        tgr.compare_with_fixture(engine_rollout, path)

@@ -1,6 +1,14 @@
-"""Checks oracle (CPU) and engine (GPU) against REAL reference fixtures tests/golden/reference_*.npz
-when they exist (made by tools/gen_golden.py where `pogema` is importable).  None can exist in this
-build container (the reference is unavailable) -> parity stays 'unpinned' and these tests skip."""
+"""Checks oracle (CPU) and engine (GPU) against REAL reference fixtures tests/golden/reference_*.npz when they exist
+(made by tools/gen_golden.py where `pogema` is importable).  None can exist in this build container (the reference is
+unavailable) -> parity stays 'unpinned' and these tests skip; tests/test_golden_pipeline.py runs the very same loader
+and comparison against fixtures generated from a stand-in package, so the procedure is known to work.
+
+Lifelong (`on_target='restart'`) fixtures: the reference draws every new target from per-agent numpy generators, a
+stream the implementations do not reproduce (docs/SPEC.md S5).  The recorded target sequence is therefore REPLAYED:
+after every step the implementation's targets are overwritten with the fixture's (`pgx_set_targets`), so positions,
+rewards, flags and observations stay comparable for the whole episode.  Only the draw itself is excluded: for a
+(step, agent) that reached its goal in that step the new target and the target plane of that step's observation are
+taken from the fixture."""
 import glob
 import os
 
@@ -10,14 +18,15 @@ import pytest
 from util import assert_rollouts_equal, engine_rollout, oracle_rollout
 
 FIXTURES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "reference_*.npz")))
+KEYS = ("obs0", "obs", "rewards", "terminated", "truncated", "is_active", "agents_xy", "targets_xy")
 
 
 def _load(path):
     z = np.load(path, allow_pickle=False)
-    ref = {k: z[k] for k in ("obs0", "obs", "rewards", "terminated", "truncated", "is_active", "agents_xy", "targets_xy")}
+    ref = {k: z[k] for k in KEYS}
     T = z["actions"].shape[0]
-    for k in ("obs", "rewards", "terminated", "truncated", "is_active", "agents_xy", "targets_xy"):
-        ref[k] = ref[k][:, None]
+    for k in KEYS[1:]:
+        ref[k] = ref[k][:, None]  # batch axis: one environment per fixture
     ref["obs0"] = ref["obs0"][None]
     ref["elapsed"] = np.arange(1, T + 1, dtype=np.int32)[:, None]
     kw = dict(obs_radius=int(z["obs_radius"]), collision_system=str(z["collision_system"]), on_target=str(z["on_target"]),
@@ -25,25 +34,28 @@ def _load(path):
     return z["obstacles"][None], z["agents_xy0"][None], z["targets_xy0"][None], z["actions"][:, None, :], ref, kw
 
 
+def compare_with_fixture(run, path):
+    """`run` = oracle_rollout or engine_rollout; raises AssertionError on the first difference."""
+    obstacles, agents, targets, actions, ref, kw = _load(path)
+    lifelong = kw["on_target"] == "restart"
+    got = run(obstacles, agents, targets, actions, inject_targets=ref["targets_xy"] if lifelong else None, **kw)
+    got = {k: v for k, v in got.items() if k in ref}
+    if lifelong:
+        drew = ref["rewards"] > 0  # [T, 1, A]: reached its goal in this step -> the reference drew a new target
+        got["targets_xy"] = np.where(drew[..., None], ref["targets_xy"], got["targets_xy"])
+        got["obs"] = got["obs"].copy()
+        got["obs"][:, :, :, 2] = np.where(drew[..., None, None], ref["obs"][:, :, :, 2], got["obs"][:, :, :, 2])
+    assert_rollouts_equal(ref, got, os.path.basename(path))
+
+
 @pytest.mark.skipif(not FIXTURES, reason="no reference fixtures: the reference is not available in this container")
 @pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p) for p in FIXTURES])
 def test_oracle_matches_reference_fixture(path):
-    obstacles, agents, targets, actions, ref, kw = _load(path)
-    if kw["on_target"] == "restart":
-        ref.pop("targets_xy")  # lifelong target stream is build-defined (DESIGN.md open question 5)
-    got = oracle_rollout(obstacles, agents, targets, actions, **kw)
-    for k in list(got):
-        if k not in ref:
-            got.pop(k)
-    assert_rollouts_equal({**got, **ref}, got, os.path.basename(path))
+    compare_with_fixture(oracle_rollout, path)
 
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not FIXTURES, reason="no reference fixtures: the reference is not available in this container")
 @pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p) for p in FIXTURES])
 def test_engine_matches_reference_fixture(path):
-    obstacles, agents, targets, actions, ref, kw = _load(path)
-    if kw["on_target"] == "restart":
-        pytest.skip("lifelong target stream is build-defined")
-    got = engine_rollout(obstacles, agents, targets, actions, **kw)
-    assert_rollouts_equal(ref, got, os.path.basename(path))
+    compare_with_fixture(engine_rollout, path)

@@ -48,8 +48,11 @@ def _oracle_semantics(semantics):
 
 
 def oracle_rollout(obstacles, agents, targets, actions, *, obs_radius, collision_system, on_target,
-                   max_episode_steps, auto_reset, seed=0, env_index_base=0, empty_outside=True, semantics=None):
-    """Returns dict of arrays [T, B, ...] from the pure-Python oracle."""
+                   max_episode_steps, auto_reset, seed=0, env_index_base=0, empty_outside=True, semantics=None,
+                   inject_targets=None):
+    """Returns dict of arrays [T, B, ...] from the pure-Python oracle.  `inject_targets` [T, B, A, 2]: after step t the
+    targets are overwritten with inject_targets[t] (replay of a recorded lifelong target sequence); the returned
+    `targets_xy` are the ones the implementation itself produced, before the overwrite."""
     T, B, A = actions.shape
     W = 2 * obs_radius + 1
     envs = [PogemaOracle(obstacles[b], agents[b], targets[b], obs_radius=obs_radius,
@@ -82,6 +85,8 @@ def oracle_rollout(obstacles, agents, targets, actions, *, obs_radius, collision
             out["agents_xy"][t, b] = st["agents_xy"]
             out["targets_xy"][t, b] = st["targets_xy"]
             out["elapsed"][t, b] = st["elapsed"]
+            if inject_targets is not None:
+                e.set_targets(inject_targets[t, b])
     return out
 
 
@@ -121,8 +126,8 @@ def c_oracle_rollout(obstacles, agents, targets, actions, *, obs_radius, collisi
 
 def engine_rollout(obstacles, agents, targets, actions, *, obs_radius, collision_system, on_target,
                    max_episode_steps, auto_reset, seed=0, env_index_base=0, action_dtype="int64",
-                   device="cuda:0", obs_dtype=None, empty_outside=True, semantics=None):
-    """Same rollout through the HIP engine (C-ABI via pogema_amd.VecPogema)."""
+                   device="cuda:0", obs_dtype=None, empty_outside=True, semantics=None, inject_targets=None):
+    """Same rollout through the HIP engine (C-ABI via pogema_amd.VecPogema); `inject_targets` as in oracle_rollout."""
     import torch
     from pogema_amd import GridConfig, VecPogema
     T, B, A = actions.shape
@@ -161,6 +166,8 @@ def engine_rollout(obstacles, agents, targets, actions, *, obs_radius, collision
         out["agents_xy"][t] = st["agents_xy"].cpu().numpy()
         out["targets_xy"][t] = st["targets_xy"].cpu().numpy()
         out["elapsed"][t] = st["elapsed"].cpu().numpy()
+        if inject_targets is not None:
+            env.set_targets(inject_targets[t])
     env.close()
     return out
 

@@ -18,7 +18,7 @@ variants = sys.argv[2:]
 batch, size, agents, r = WL[wl]
 envs = []
 for v in variants:
-    for k in ("PGX_FLAGS", "PGX_EPW", "PGX_STAGGER", "PGX_LDS_MIN", "PGX_WAVES"):
+    for k in ("PGX_FLAGS", "PGX_EPW", "PGX_STAGGER", "PGX_LDS_MIN", "PGX_WAVES", "PGX_STORE", "PGX_TEAM"):
         os.environ.pop(k, None)
     for kv in v.split(","):
         if kv:
@@ -33,6 +33,7 @@ for v in variants:
         env._bufs = [(envs[0]._bufs[k][0],) + env._alloc_outputs(False)[1:] for k in range(2)]
     else:
         env._outputs()
+        print("buffers:", getattr(env, "placement", None))
     envs.append(env)
 acts = [torch.randint(0, 5, (batch, agents), device="cuda") for _ in range(8)]
 rounds, steps = 12, 60
@@ -48,5 +49,16 @@ for rd in range(rounds):
         e1.record()
         torch.cuda.synchronize()
         times[i, rd] = e0.elapsed_time(e1) / steps * 1e3
+# floor: observation-only passes (no actions, no collision resolve, no state stores) into the same two buffers
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+bufs = [envs[0]._bufs[0][0], envs[0]._bufs[1][0]]
+for k in range(5):
+    envs[0].observe(out=bufs[k & 1])
+e0.record()
+for k in range(60):
+    envs[0].observe(out=bufs[k & 1])
+e1.record()
+torch.cuda.synchronize()
+print(f"{wl} observe-only into the same buffers: {e0.elapsed_time(e1) / 60 * 1e3:8.2f} us")
 for v, t in zip(variants, times):
     print(f"{wl} {v:24s} median {np.median(t):8.2f} us  min {t.min():8.2f}  max {t.max():8.2f}")

@@ -20,52 +20,123 @@ def _engine(B, size, A, r, collision, on_target, max_steps, auto_reset, obstacle
     return env, obs0
 
 
+def goal_seeking_actions(rng, agents_xy, targets_xy, p_random=0.5):
+    """Uniform random moves mixed with moves along the larger coordinate difference to the target (no obstacle
+    awareness), so that within a few steps agents arrive, finish, get new targets and pile up around goals."""
+    d = targets_xy.astype(np.int64) - agents_xy.astype(np.int64)
+    along_x = np.abs(d[..., 0]) >= np.abs(d[..., 1])
+    greedy = np.where(along_x, np.where(d[..., 0] < 0, 1, 2), np.where(d[..., 1] < 0, 3, 4))
+    greedy = np.where((d == 0).all(axis=-1), 0, greedy)
+    rnd = rng.integers(0, 5, size=greedy.shape)
+    return np.where(rng.random(greedy.shape) < p_random, rnd, greedy).astype(np.int64)
+
+
+def _assert_same_step(name, t, env, ref, out, rout, check_obs):
+    obs, rew, term, trunc, info = out
+    robs, rrew, rterm, rtrunc, ract = rout
+    st, rst = env.get_state(), ref.get_state()
+    assert np.array_equal(st["agents_xy"].cpu().numpy(), rst["agents_xy"]), f"{name} step {t}: positions"
+    assert np.array_equal(st["targets_xy"].cpu().numpy(), rst["targets_xy"]), f"{name} step {t}: targets"
+    assert np.array_equal(st["is_active"].cpu().numpy(), rst["is_active"]), f"{name} step {t}: is_active"
+    assert np.array_equal(st["elapsed"].cpu().numpy(), rst["elapsed"]), f"{name} step {t}: elapsed"
+    assert np.array_equal(term.cpu().numpy(), rterm) and np.array_equal(trunc.cpu().numpy(), rtrunc), f"{name} step {t}: flags"
+    assert np.array_equal(info["is_active"].cpu().numpy(), ract)
+    np.testing.assert_allclose(rew.cpu().numpy(), rrew, rtol=0, atol=1e-6)
+    done = info["episode_done"].cpu().numpy().astype(bool)
+    assert np.array_equal(done, ref.episode_done.astype(bool)), f"{name} step {t}: episode_done"
+    np.testing.assert_allclose(info["metrics"].cpu().numpy()[done], ref.metrics[done], rtol=1e-6, atol=1e-6)
+    if check_obs:
+        assert np.array_equal(obs.cpu().numpy(), robs), f"{name} step {t}: observations"
+    return rst
+
+
 FULL = [
-    # name, batch, size, agents, r, steps, compare_obs_every_step
-    ("configs2", 8192, 64, 64, 5, 3),
-    ("configs3_shard", 8192, 32, 16, 5, 4),
-    ("configs4", 4096, 256, 256, 7, 2),
+    # name, batch, size, agents, r, steps, max_episode_steps, on_target modes
+    ("configs2", 8192, 64, 64, 5, 16, 8, ("finish", "restart", "nothing")),
+    ("configs3_shard", 8192, 32, 16, 5, 16, 8, ("finish", "restart")),
+    ("configs4", 4096, 256, 256, 7, 4, 3, ("finish",)),
 ]
+FULL_CASES = [(c, ot) for c in FULL for ot in c[7]]
 
 
-@pytest.mark.parametrize("cfg", FULL, ids=[c[0] for c in FULL])
+@pytest.mark.parametrize("cfg,on_target", FULL_CASES, ids=[f"{c[0]}-{ot}" for c, ot in FULL_CASES])
 @pytest.mark.parametrize("collision", ["soft", "priority", "block_both"])
-def test_full_size_parity_with_c_oracle(cfg, collision):
+def test_full_size_parity_with_c_oracle(cfg, on_target, collision):
+    """The FULL batch of BASELINE.json configs[2] / configs[3] (one GPU's shard) / configs[4] against the plain-C oracle:
+    every episode mode, max_episode_steps 8 and 16 steps (two episodes through the auto-reset) for configs[2]/[3],
+    goal-seeking actions so that arrivals, finished/hidden agents, lifelong re-targets and cooperative termination
+    all occur; state, flags, rewards and fused metrics every step, the full observation tensor on the first, the
+    auto-reset and the last step (collision system 'soft' only: the observation path is the same for all three)."""
     from oracle.c_oracle import COracle
-    name, B, size, A, r, T = cfg
+    name, B, size, A, r, T, max_steps, _ = cfg
     obstacles, agents, targets = generate_instances(B, size, size, A, 0.3, 7)
     rng = np.random.default_rng(3)
-    actions = rng.integers(0, 5, size=(T, B, A)).astype(np.int64)
-    ref = COracle(B, size, size, A, r, collision, "finish", 2, True)  # max_episode_steps=2: auto-reset is exercised
+    ref = COracle(B, size, size, A, r, collision, on_target, max_steps, True, seed=9, env_index_base=5)
     ref_obs0 = ref.reset(obstacles, agents, targets)
-    env, obs0 = _engine(B, size, A, r, collision, "finish", 2, True, obstacles, agents, targets)
-    check_obs = collision == "soft"  # the observation path is identical for all systems; compare it once
-    if check_obs:
+    from pogema_amd import GridConfig, VecPogema
+    gc = GridConfig(size=size, num_agents=A, obs_radius=r, collision_system=collision, on_target=on_target,
+                    max_episode_steps=max_steps, seed=9, density=0.3)
+    env = VecPogema(gc, batch=B, auto_reset=True, env_index_base=5)
+    obs0 = env.reset_from_state(obstacles, agents, targets, validate=False)
+    obs_steps = {0, max_steps - 1, T - 1} if collision == "soft" else set()
+    if obs_steps:
         assert np.array_equal(obs0.cpu().numpy(), ref_obs0)
     del ref_obs0, obs0
     threads = min(32, len(__import__("os").sched_getaffinity(0)))
+    state = ref.get_state()
+    events = 0
     for t in range(T):
-        robs, rrew, rterm, rtrunc, ract = ref.step(actions[t], nthreads=threads, compute_obs=check_obs)
-        obs, rew, term, trunc, info = env.step(torch.from_numpy(actions[t]).cuda(), compute_obs=check_obs)
-        st, rst = env.get_state(), ref.get_state()
-        assert np.array_equal(st["agents_xy"].cpu().numpy(), rst["agents_xy"]), f"{name} step {t}: positions"
-        assert np.array_equal(st["targets_xy"].cpu().numpy(), rst["targets_xy"])
-        assert np.array_equal(st["is_active"].cpu().numpy(), rst["is_active"])
-        assert np.array_equal(st["elapsed"].cpu().numpy(), rst["elapsed"])
-        assert np.array_equal(term.cpu().numpy(), rterm) and np.array_equal(trunc.cpu().numpy(), rtrunc)
-        assert np.array_equal(info["is_active"].cpu().numpy(), ract)
-        np.testing.assert_allclose(rew.cpu().numpy(), rrew, rtol=0, atol=1e-6)
-        if check_obs:
-            assert np.array_equal(obs.cpu().numpy(), robs), f"{name} step {t}: observations"
-            del obs, robs
+        acts = goal_seeking_actions(rng, state["agents_xy"], state["targets_xy"])
+        check_obs = t in obs_steps
+        rout = ref.step(acts, nthreads=threads, compute_obs=check_obs)
+        out = env.step(torch.from_numpy(acts).cuda(), compute_obs=check_obs)
+        state = _assert_same_step(f"{name}/{on_target}/{collision}", t, env, ref, out, rout, check_obs)
+        # rewarded arrivals; cooperative finish pays only when ALL agents of an env are home at once (practically never
+        # at 64 agents), so there the agents standing on their goals -- visible, unrewarded -- are what is exercised
+        events += int(rout[1].sum()) if on_target != "nothing" else int((state["agents_xy"] == state["targets_xy"]).all(-1).sum())
+    assert events > 0, "the rollout must contain arrivals (otherwise the episode logic was not exercised)"
     env.close()
     ref.close()
 
 
-@pytest.mark.parametrize("collision", ["priority", "block_both", "soft"])
-@pytest.mark.parametrize("on_target", ["finish", "restart", "nothing"])
-def test_invariants_configs2(collision, on_target):
-    B, size, A, r, T = 8192, 64, 64, 5, 40
+@pytest.mark.parametrize("collision", ["soft", "priority", "block_both"])
+def test_configs4_geometry_soak_with_c_oracle(collision):
+    """configs[4] geometry (256x256 maps, 256 agents = 4 waves per environment with the collision closure and the
+    env-wide reductions going through LDS, obs_radius 7) over 64 steps and several episodes: 256 environments, finish
+    mode with max_episode_steps 24 for all systems plus a lifelong run for 'soft'; observations every 16th step."""
+    from oracle.c_oracle import COracle
+    from pogema_amd import GridConfig, VecPogema
+    B, size, A, r, T, max_steps = 256, 256, 256, 7, 64, 24
+    obstacles, agents, targets = generate_instances(B, size, size, A, 0.3, 21)
+    threads = min(32, len(__import__("os").sched_getaffinity(0)))
+    for on_target in (("finish", "restart") if collision == "soft" else ("finish",)):
+        rng = np.random.default_rng(17)
+        ref = COracle(B, size, size, A, r, collision, on_target, max_steps, True, seed=3, env_index_base=11)
+        ref.reset(obstacles, agents, targets)
+        gc = GridConfig(size=size, num_agents=A, obs_radius=r, collision_system=collision, on_target=on_target,
+                        max_episode_steps=max_steps, seed=3, density=0.3)
+        env = VecPogema(gc, batch=B, auto_reset=True, env_index_base=11)
+        env.reset_from_state(obstacles, agents, targets, validate=False)
+        state = ref.get_state()
+        for t in range(T):
+            acts = goal_seeking_actions(rng, state["agents_xy"], state["targets_xy"], p_random=0.3)
+            check_obs = t % 16 == 15 or t == max_steps - 1
+            rout = ref.step(acts, nthreads=threads, compute_obs=check_obs)
+            out = env.step(torch.from_numpy(acts).cuda(), compute_obs=check_obs)
+            state = _assert_same_step(f"configs4-soak/{on_target}/{collision}", t, env, ref, out, rout, check_obs)
+        env.close()
+        ref.close()
+
+
+INVARIANT_GEOMS = {"configs2": (8192, 64, 64, 5, 40), "configs4": (4096, 256, 256, 7, 8)}
+INVARIANT_CASES = [("configs2", c, o) for c in ("priority", "block_both", "soft") for o in ("finish", "restart", "nothing")] + \
+                  [("configs4", c, o) for c, o in (("soft", "finish"), ("priority", "restart"), ("block_both", "nothing"),
+                                                   ("soft", "restart"))]
+
+
+@pytest.mark.parametrize("geom,collision,on_target", INVARIANT_CASES, ids=["-".join(c) for c in INVARIANT_CASES])
+def test_invariants_full_size(geom, collision, on_target):
+    B, size, A, r, T = INVARIANT_GEOMS[geom]
     obstacles, agents, targets = generate_instances(B, size, size, A, 0.3, 11)
     env, obs = _engine(B, size, A, r, collision, on_target, 16, True, obstacles, agents, targets, seed=5)
     d_obst = torch.from_numpy(obstacles).cuda()

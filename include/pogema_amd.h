@@ -249,6 +249,30 @@ void* pgx_buffers_ptr(pgx_buffers* pool, int index); /* device pointer of buffer
 int pgx_buffers_get_info(pgx_buffers* pool, pgx_buffers_info* info);
 int pgx_buffers_destroy(pgx_buffers* pool);          /* synchronises the device, then unmaps and frees        */
 
+/* ---- numpy-compatible random primitives ----------------------------------------------------------- */
+/* Upstream POGEMA draws everything random from numpy Generators (np.random.default_rng(seed): SeedSequence -> PCG64 ->
+ * integers / choice / shuffle / binomial / random; pogema/generator.py and the per-agent generators of PogemaLifeLong).
+ * The engine's own generator and lifelong streams are counter-based and different (docs/SPEC.md S5, S6); these entry
+ * points provide the numpy PRIMITIVES bit for bit -- pinned against numpy itself (tests/golden/numpy_rng_vectors.npz,
+ * tests/test_nprng*.py) -- so that a numpy-stream mode can follow the upstream call sequence once the source is at hand
+ * (pgx_config.lifelong_rng = PGX_LIFELONG_RNG_NUMPY already uses them for the lifelong target draw).
+ * `streams` independent generators default_rng(seeds[s]) are each advanced `draws` times:
+ *   PGX_NP_UINT64       raw 64-bit outputs (bit_generator.random_raw)          out u64 [streams, draws]
+ *   PGX_NP_RANDOM       Generator.random()                                     out f64 [streams, draws]
+ *   PGX_NP_INTEGERS     Generator.integers(0, n) = Generator.choice(n)         out i64 [streams, draws]
+ *   PGX_NP_BINOMIAL1    Generator.binomial(1, p)  (generate_obstacles)         out i64 [streams, draws]
+ *   PGX_NP_PERMUTATION  Generator.permutation(draws) = shuffle(arange(draws))  out i64 [streams, draws]
+ * pgx_np_streams: device pointers, one GPU thread per stream, asynchronous on `stream`; pgx_np_streams_host: the same
+ * arithmetic on the host (host pointers). */
+#define PGX_NP_UINT64 0
+#define PGX_NP_RANDOM 1
+#define PGX_NP_INTEGERS 2
+#define PGX_NP_BINOMIAL1 3
+#define PGX_NP_PERMUTATION 4
+int pgx_np_streams(const uint64_t* seeds, int64_t streams, int32_t op, uint64_t n, double p, int64_t draws, void* out,
+                   void* stream);
+int pgx_np_streams_host(const uint64_t* seeds, int64_t streams, int32_t op, uint64_t n, double p, int64_t draws, void* out);
+
 /* ---- state export ------------------------------------------------------------------------------- */
 /* Replaces `Grid.get_agents_xy` / `get_targets_xy` / `is_active` / the occupancy array (`positions`).
  * Any pointer may be NULL.  All device pointers.

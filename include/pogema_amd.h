@@ -63,6 +63,17 @@ extern "C" {
 #define PGX_BAD_ACTION_FLAG 1        /* Q7 alternative: still a noop on the device, but counted -- pgx_bad_action_count()
                                         lets the host raise the reference's IndexError                               */
 
+/* Stream of the lifelong (on_target = RESTART) target draw.
+ *   BUILD  the build's own counter-based stream (docs/SPEC.md S5), keyed by (seed, global env, agent, draw number)
+ *   NUMPY  per-agent numpy generators as upstream `PogemaLifeLong._initialize_grid` sets them up (recalled, conf.
+ *          medium): main = default_rng(env_seed); seeds = main.integers(2^31 - 1, size=num_agents);
+ *          generator[a] = default_rng(seeds[a]); new target = component[generator[a].integers(0, len(component))]
+ *          (= `rnd_generator.choice(component, 1)`), re-created at every reset of the env.  env_seed = cfg.seed + global
+ *          env index.  The numpy arithmetic is exact (pgx_np_streams); what stays build-defined is the ORDER of a
+ *          component's cells (row-major here; upstream: the order its BFS produced). */
+#define PGX_LIFELONG_RNG_BUILD 0
+#define PGX_LIFELONG_RNG_NUMPY 1
+
 /* dtype of the `actions` buffer handed to pgx_step */
 #define PGX_ACTION_I8 0
 #define PGX_ACTION_I32 1
@@ -103,7 +114,7 @@ typedef struct pgx_config {
     int32_t soft_vertex_rule;  /* PGX_SOFT_*        (0 = recalled literal algorithm)                    */
     int32_t coop_reward;       /* PGX_COOP_REWARD_* (0 = recalled)                                       */
     int32_t bad_action;        /* PGX_BAD_ACTION_*  (0 = noop)                                           */
-    int32_t reserved0;
+    int32_t lifelong_rng;      /* PGX_LIFELONG_RNG_* (0 = the build's counter-based stream)              */
 } pgx_config;
 
 typedef struct pgx_env pgx_env; /* opaque */

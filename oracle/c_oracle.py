@@ -58,7 +58,10 @@ class COracle:
 
     def __init__(self, batch, height, width, num_agents, obs_radius, collision_system="priority", on_target="finish",
                  max_episode_steps=64, auto_reset=False, seed=0, env_index_base=0, empty_outside=True,
-                 outside_density=0.0, soft_vertex_rule="lowest_index", coop_reward="all_solved", bad_action="noop"):
+                 outside_density=0.0, soft_vertex_rule="lowest_index", coop_reward="all_solved", bad_action="noop",
+                 lifelong_rng="build"):
+        if lifelong_rng != "build":
+            raise NotImplementedError("the plain-C port has the build's lifelong stream only; use the Python oracle")
         self.lib = load()
         self.B, self.H, self.Wd, self.A, self.r = batch, height, width, num_agents, obs_radius
         self.W = 2 * obs_radius + 1

@@ -197,10 +197,12 @@ class PogemaOracle:
     def __init__(self, obstacles, agents_xy, targets_xy, obs_radius=5, collision_system="priority",
                  on_target="finish", max_episode_steps=64, auto_reset=False, seed=0, env_index=0,
                  empty_outside=True, outside_density=0.0, epoch=0, soft_vertex_rule="lowest_index",
-                 coop_reward="all_solved", bad_action="noop"):
+                 coop_reward="all_solved", bad_action="noop", lifelong_rng="build"):
         assert collision_system in COLLISION_SYSTEMS and on_target in ON_TARGET
         assert soft_vertex_rule in SOFT_VERTEX_RULES and coop_reward in COOP_REWARDS and bad_action in BAD_ACTIONS
         self.soft_vertex_rule, self.coop_reward, self.bad_action = soft_vertex_rule, coop_reward, bad_action
+        assert lifelong_rng in ("build", "numpy")
+        self.lifelong_rng = lifelong_rng
         self._init_args = (np.array(obstacles, copy=True), [tuple(map(int, p)) for p in agents_xy],
                            [tuple(map(int, p)) for p in targets_xy])
         self.obs_radius = int(obs_radius)
@@ -237,6 +239,11 @@ class PogemaOracle:
             # reset; the build keeps a monotone per-agent counter instead.
             if not hasattr(self, "_target_counter"):
                 self._target_counter = [0] * self.num_agents
+            if self.lifelong_rng == "numpy":
+                # upstream PogemaLifeLong._initialize_grid (recalled, conf. medium), with numpy itself:
+                main_rng = np.random.default_rng(self.seed + self.env_index)
+                seeds = main_rng.integers(np.iinfo(np.int32).max, size=self.num_agents)
+                self._random_generators = [np.random.default_rng(int(s)) for s in seeds]
         return self._obs()
 
     # -- A12 -----------------------------------------------------------------------------------
@@ -466,6 +473,12 @@ class PogemaOracle:
         r = self.obs_radius
         x, y = self.grid.positions_xy[agent_idx]
         comp = self._comp_points[self._labels[x - r, y - r]]
+        if self.lifelong_rng == "numpy":
+            # upstream generate_new_target: `tuple(*rnd_generator.choice(component, 1))` (the component's cell ORDER is
+            # build-defined: row-major)
+            tx, ty = (int(v) for v in self._random_generators[agent_idx].choice(comp, 1)[0])
+            self._target_counter[agent_idx] += 1
+            return (tx + r, ty + r)
         k = lifelong_draw(self.seed, self.env_index, agent_idx, self._target_counter[agent_idx], len(comp))
         self._target_counter[agent_idx] += 1
         tx, ty = comp[k]

@@ -20,6 +20,7 @@ ACTION_DTYPES = {"int8": 0, "int32": 1, "int64": 2}
 SOFT_VERTEX_RULES = {"lowest_index": 0, "all_stay": 1}
 COOP_REWARDS = {"all_solved": 0, "per_agent": 1}
 BAD_ACTIONS = {"noop": 0, "flag": 1}
+LIFELONG_RNGS = {"build": 0, "numpy": 1}
 def _obs_dtypes():
     import torch
     return {torch.float32: 0, torch.uint8: 1}
@@ -73,7 +74,7 @@ class PgxConfig(C.Structure):
         ("max_episode_steps", C.c_int32), ("auto_reset", C.c_int32), ("obs_dtype", C.c_int32),
         ("seed", C.c_uint64), ("env_index_base", C.c_int64),
         ("random_outside", C.c_int32), ("outside_density", C.c_float),
-        ("soft_vertex_rule", C.c_int32), ("coop_reward", C.c_int32), ("bad_action", C.c_int32), ("reserved0", C.c_int32),
+        ("soft_vertex_rule", C.c_int32), ("coop_reward", C.c_int32), ("bad_action", C.c_int32), ("lifelong_rng", C.c_int32),
     ]
 
 

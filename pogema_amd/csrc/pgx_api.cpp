@@ -98,6 +98,7 @@ struct pgx_env {
     unsigned long long* dbg = nullptr;
     size_t dbg_elems = 0;
     uint32_t *comp_begin = nullptr, *comp_len = nullptr, *comp_cells = nullptr, *tcount = nullptr;
+    pgx::NpGen *np_state = nullptr, *np_state0 = nullptr;  // lifelong_rng = NUMPY
     // reset path (pgx_reset.hip): unpadded u8 maps, per-env flags / generation counters, chunked scratch
     uint8_t* map_u8 = nullptr;            // [B][H*W]
     uint8_t *todo = nullptr, *regen = nullptr;  // [B]
@@ -134,7 +135,7 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
     if (cfg->random_outside && !(cfg->outside_density >= 0.0f && cfg->outside_density <= 1.0f))
         return fail(PGX_E_INVALID, "outside_density %.3f outside [0, 1]", (double)cfg->outside_density);
     if (cfg->soft_vertex_rule < 0 || cfg->soft_vertex_rule > 1 || cfg->coop_reward < 0 || cfg->coop_reward > 1 ||
-        cfg->bad_action < 0 || cfg->bad_action > 1)
+        cfg->bad_action < 0 || cfg->bad_action > 1 || cfg->lifelong_rng < 0 || cfg->lifelong_rng > 1)
         return fail(PGX_E_INVALID, "unknown semantics switch (soft_vertex_rule %d, coop_reward %d, bad_action %d)",
                     cfg->soft_vertex_rule, cfg->coop_reward, cfg->bad_action);
     if (cfg->obs_dtype != PGX_OBS_F32 && cfg->obs_dtype != PGX_OBS_U8)
@@ -209,6 +210,10 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
         alloc((void**)&e->comp_len, cells * sizeof(uint32_t));
         alloc((void**)&e->comp_cells, cells * sizeof(uint32_t));
         alloc((void**)&e->tcount, BA * sizeof(uint32_t));
+        if (cfg->lifelong_rng == PGX_LIFELONG_RNG_NUMPY) {
+            alloc((void**)&e->np_state, BA * sizeof(pgx::NpGen));
+            alloc((void**)&e->np_state0, BA * sizeof(pgx::NpGen));
+        }
     }
     if (err != hipSuccess) {
         const char* msg = hipGetErrorString(err);
@@ -217,6 +222,9 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
     }
     err = hipMemset(e->regen_fail, 0, sizeof(uint32_t));
     if (err == hipSuccess) err = hipMemset(e->bad_count, 0, sizeof(uint32_t));
+    if (err == hipSuccess && e->np_state0)
+        err = pgx::launch_init_np_lifelong(e->np_state0, cfg->seed, cfg->env_index_base, cfg->batch, A, nullptr);
+    if (err == hipSuccess && e->np_state0) err = hipStreamSynchronize(nullptr);
     if (err == hipSuccess) err = pgx::prepare_step(e->geo);
     if (err != hipSuccess) {
         const char* msg = hipGetErrorString(err);
@@ -237,7 +245,7 @@ int pgx_destroy(pgx_env* e) {
     if (!e) return PGX_OK;
     DeviceGuard guard(e->device);
     void* ptrs[] = {e->obst,   e->pos,     e->tgt,        e->pos0,     e->tgt0,       e->active,
-                    e->elapsed, e->comp_begin, e->comp_len, e->comp_cells, e->tcount, e->dbg, e->macc,
+                    e->elapsed, e->comp_begin, e->comp_len, e->comp_cells, e->tcount, e->np_state, e->np_state0, e->dbg, e->macc,
                     e->map_u8, e->todo, e->regen, e->epoch, e->fail_count, e->regen_fail, e->bad_count, e->labels, e->pending,
                     e->scratch_map};
     for (void* p : ptrs)
@@ -318,6 +326,7 @@ static pgx::ResetParams reset_params(const pgx_env* e) {
     p.scratch_map = e->scratch_map; p.labels = e->labels; p.pending = e->pending;
     p.map_u8 = e->map_u8; p.obst_bm = e->obst;
     p.pos = e->pos; p.tgt = e->tgt; p.pos0 = e->pos0; p.tgt0 = e->tgt0; p.active = e->active; p.tcount = e->tcount;
+    p.np_state = e->np_state; p.np_state0 = e->np_state0;
     p.elapsed = e->elapsed; p.macc = e->macc;
     p.comp_begin = e->comp_begin; p.comp_len = e->comp_len; p.comp_cells = e->comp_cells;
     p.fail_count = e->fail_count;
@@ -339,7 +348,7 @@ int pgx_reset_from_state(pgx_env* e, const uint8_t* obstacles, const int32_t* ag
     PGX_HIP(pgx::launch_pack_obstacles(e->map_u8, nullptr, e->obst, c.batch, c.height, c.width, c.obs_radius, e->wpr,
                                        e->bmw, outside_params(e), s));
     PGX_HIP(pgx::launch_pack_agents(agent_xy, target_xy, e->pos, e->tgt, e->pos0, e->tgt0, e->active, e->tcount, BA,
-                                    c.obs_radius, s));
+                                    c.obs_radius, s, e->np_state, e->np_state0));
     PGX_HIP(pgx::launch_zero_i32(e->elapsed, B, s));
     PGX_HIP(pgx::launch_zero_i32(reinterpret_cast<int32_t*>(e->macc), B * 4, s));
     if (c.on_target == PGX_ON_TARGET_RESTART) {  // component tables of PogemaLifeLong, built on the device
@@ -457,6 +466,7 @@ std::vector<Segment> snapshot_segments(pgx_env* e) {
     };
     if (c.on_target == PGX_ON_TARGET_RESTART) {
         seg.push_back({e->tcount, BA * 4});
+        if (e->np_state) seg.push_back({e->np_state, BA * sizeof(pgx::NpGen)});
         seg.push_back({e->comp_begin, B * cells * 4});
         seg.push_back({e->comp_len, B * cells * 4});
         seg.push_back({e->comp_cells, B * cells * 4});
@@ -582,6 +592,8 @@ static void fill_params(const pgx_env* e, pgx::StepParams& p) {
     p.comp_len = e->comp_len;
     p.comp_cells = e->comp_cells;
     p.tcount = e->tcount;
+    p.np_state = e->np_state;
+    p.np_state0 = e->np_state0;
     p.dbg = e->dbg;
     p.macc = e->macc;
     p.metrics_out = e->metrics_out;

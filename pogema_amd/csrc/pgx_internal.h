@@ -47,6 +47,11 @@ __host__ __device__ inline uint32_t gen_outside_bit(uint64_t h, int x, int y, in
     return (gen_sm64(h ^ (uint64_t)(x * PW + y)) >> 40) < thr ? 1u : 0u;
 }
 
+// One numpy Generator (PCG64) per agent, lifelong_rng = NUMPY: {state hi, state lo, inc hi, inc lo, has_uint32 << 32 | uinteger}
+struct NpGen {
+    uint64_t w[5];
+};
+
 // Kernel argument block of the step kernel (passed by value: lands in SGPRs / kernarg segment).
 struct StepParams {
     // geometry
@@ -81,6 +86,8 @@ struct StepParams {
     const uint32_t* comp_len;    // [B][H*W]  size of the cell's component
     const uint32_t* comp_cells;  // [B][H*W]  unpadded packed cells grouped by component, row-major inside
     uint32_t* tcount;            // [B][A]    targets drawn so far
+    NpGen* np_state;             // [B][A]    lifelong_rng = NUMPY: the agents' generators (null otherwise)
+    const NpGen* np_state0;      // [B][A]    ... as they are right after a reset of the env
     // metric accumulators (pogema/wrappers/metrics.py): {agents solved, sum of solve steps, max solve step, lifelong goals}
     int4* macc;                  // [B]
     float* metrics_out;          // [B][6] ISR, CSR, ep_length, SoC, makespan, avg_throughput (caller-owned, may be null)
@@ -140,6 +147,8 @@ struct ResetParams {
     uint32_t *pos, *tgt, *pos0, *tgt0;
     uint8_t* active;
     uint32_t* tcount;           // may be null
+    NpGen* np_state;            // may be null (lifelong_rng = NUMPY)
+    const NpGen* np_state0;
     int32_t* elapsed;
     int4* macc;
     uint32_t *comp_begin, *comp_len, *comp_cells;  // lifelong only
@@ -151,7 +160,9 @@ hipError_t launch_reset_begin(const uint8_t* mask, uint8_t* todo, uint8_t* regen
 hipError_t launch_reset_env(const ResetParams& p, hipStream_t s);
 hipError_t launch_pack_agents(const int32_t* agent_xy, const int32_t* target_xy, uint32_t* pos, uint32_t* tgt,
                               uint32_t* pos0, uint32_t* tgt0, uint8_t* active, uint32_t* tcount, size_t n,
-                              int r, hipStream_t stream);
+                              int r, hipStream_t stream, NpGen* np_state = nullptr, const NpGen* np_state0 = nullptr);
+// np_state0[env][a] = generator of agent a of global env (env_index_base + env) right after a reset (lifelong_rng = NUMPY)
+hipError_t launch_init_np_lifelong(NpGen* np_state0, uint64_t seed, int64_t env_index_base, int batch, int A, hipStream_t stream);
 hipError_t launch_zero_i32(int32_t* v, size_t n, hipStream_t stream);
 hipError_t launch_set_targets(const int32_t* target_xy, const uint8_t* mask, uint32_t* tgt, size_t n, int r,
                               hipStream_t stream);

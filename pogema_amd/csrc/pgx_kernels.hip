@@ -25,6 +25,7 @@
 #include <utility>
 
 #include "pgx_internal.h"
+#include "pgx_nprng.h"
 
 namespace pgx {
 
@@ -42,6 +43,22 @@ __device__ __forceinline__ uint32_t lifelong_draw(uint64_t seed, uint64_t env_in
     h = splitmix64(h ^ env_index);
     h = splitmix64(h ^ (((uint64_t)agent << 32) | counter));
     return (uint32_t)(((h >> 32) * (uint64_t)n) >> 32);
+}
+
+__device__ __forceinline__ pgxnp::Pcg64 np_unpack(const NpGen& s) {
+    pgxnp::Pcg64 g;
+    g.state = ((pgxnp::u128)s.w[0] << 64) | s.w[1];
+    g.inc = ((pgxnp::u128)s.w[2] << 64) | s.w[3];
+    g.has_uint32 = (uint32_t)(s.w[4] >> 32);
+    g.uinteger = (uint32_t)s.w[4];
+    return g;
+}
+__host__ __device__ inline NpGen np_pack(const pgxnp::Pcg64& g) {
+    NpGen s;
+    s.w[0] = (uint64_t)(g.state >> 64); s.w[1] = (uint64_t)g.state;
+    s.w[2] = (uint64_t)(g.inc >> 64); s.w[3] = (uint64_t)g.inc;
+    s.w[4] = ((uint64_t)g.has_uint32 << 32) | g.uinteger;
+    return s;
 }
 
 // packed cell in HBM/LDS: (x << 16) | y in PADDED coordinates.
@@ -485,7 +502,14 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
                 const uint32_t begin = p.comp_begin[ci];
                 const uint32_t len = p.comp_len[ci];
                 const uint32_t cnt = p.tcount[gi];
-                const uint32_t k = lifelong_draw(p.seed, (uint64_t)(p.env_index_base + env), (uint32_t)agent, cnt, len);
+                uint32_t k;
+                if (p.np_state) {  // PGX_LIFELONG_RNG_NUMPY: generator[agent].integers(0, len) == choice(component, 1)
+                    pgxnp::Pcg64 g = np_unpack(p.np_state[gi]);
+                    k = (uint32_t)pgxnp::integers_below(g, len);
+                    p.np_state[gi] = np_pack(g);
+                } else {
+                    k = lifelong_draw(p.seed, (uint64_t)(p.env_index_base + env), (uint32_t)agent, cnt, len);
+                }
                 const uint32_t cell = p.comp_cells[(size_t)env * p.map_cells + begin + k];
                 tgt = cell + (((uint32_t)r << 16) | (uint32_t)r);
                 p.tcount[gi] = cnt + 1;
@@ -503,6 +527,7 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
                     tgt = p.tgt0[gi];
                     active = true;
                     vis = to_c22(pos);
+                    if (p.np_state) p.np_state[gi] = p.np_state0[gi];  // upstream re-creates the generators in reset()
                 }
                 p.pos[gi] = pos;
                 p.tgt[gi] = tgt;
@@ -801,7 +826,8 @@ __global__ void pack_obstacles_kernel(const uint8_t* __restrict__ obstacles, con
 __global__ void pack_agents_kernel(const int32_t* __restrict__ agent_xy, const int32_t* __restrict__ target_xy,
                                    uint32_t* __restrict__ pos, uint32_t* __restrict__ tgt,
                                    uint32_t* __restrict__ pos0, uint32_t* __restrict__ tgt0,
-                                   uint8_t* __restrict__ active, uint32_t* __restrict__ tcount, size_t n, int r) {
+                                   uint8_t* __restrict__ active, uint32_t* __restrict__ tcount, size_t n, int r,
+                                   NpGen* __restrict__ np_state, const NpGen* __restrict__ np_state0) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t pc = ((uint32_t)(agent_xy[2 * i] + r) << 16) | (uint32_t)(agent_xy[2 * i + 1] + r);
@@ -812,6 +838,19 @@ __global__ void pack_agents_kernel(const int32_t* __restrict__ agent_xy, const i
     tgt0[i] = tc;
     active[i] = 1;
     if (tcount) tcount[i] = 0u;
+    if (np_state) np_state[i] = np_state0[i];
+}
+
+// lifelong_rng = NUMPY (upstream PogemaLifeLong._initialize_grid, recalled): per env
+//   main = default_rng(seed + global env); seeds = main.integers(2^31 - 1, size=A); generator[a] = default_rng(seeds[a])
+__global__ void init_np_lifelong_kernel(NpGen* __restrict__ np_state0, uint64_t seed, int64_t env_index_base, int batch, int A) {
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= batch) return;
+    pgxnp::Pcg64 main_rng = pgxnp::default_rng(seed + (uint64_t)(env_index_base + env));
+    for (int a = 0; a < A; ++a) {
+        const uint64_t s = pgxnp::integers_below(main_rng, 2147483647ull);
+        np_state0[(size_t)env * A + a] = np_pack(pgxnp::default_rng(s));
+    }
 }
 
 // pgx_set_targets: overwrite the targets of the flagged agents (all when mask == null)
@@ -980,10 +1019,15 @@ hipError_t launch_pack_obstacles(const uint8_t* obstacles, const uint8_t* only, 
 
 hipError_t launch_pack_agents(const int32_t* agent_xy, const int32_t* target_xy, uint32_t* pos, uint32_t* tgt,
                               uint32_t* pos0, uint32_t* tgt0, uint8_t* active, uint32_t* tcount, size_t n,
-                              int r, hipStream_t stream) {
+                              int r, hipStream_t stream, NpGen* np_state, const NpGen* np_state0) {
     const int bs = 256;
     hipLaunchKernelGGL(pack_agents_kernel, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, stream, agent_xy,
-                       target_xy, pos, tgt, pos0, tgt0, active, tcount, n, r);
+                       target_xy, pos, tgt, pos0, tgt0, active, tcount, n, r, np_state, np_state0);
+    return hipGetLastError();
+}
+
+hipError_t launch_init_np_lifelong(NpGen* np_state0, uint64_t seed, int64_t env_index_base, int batch, int A, hipStream_t stream) {
+    hipLaunchKernelGGL(init_np_lifelong_kernel, dim3((batch + 63) / 64), dim3(64), 0, stream, np_state0, seed, env_index_base, batch, A);
     return hipGetLastError();
 }
 

@@ -414,6 +414,7 @@ __global__ __launch_bounds__(256) void reset_env_kernel(const ResetParams p) {
             p.tgt0[gi] = tc;
             p.active[gi] = 1;
             if (p.tcount) p.tcount[gi] = 0u;
+            if (p.np_state) p.np_state[gi] = p.np_state0[gi];
         }
         if (tid == 0) {
             p.todo[env] = 0;

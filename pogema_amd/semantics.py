@@ -17,6 +17,14 @@ matrix -- so that pinning against the real package is a flip here, not a kernel 
                   'flag'       : the device still treats it as a noop but counts it, and `step()` raises the
                                  reference's IndexError (`MOVES[action]`) -- costs one host sync per step.
 
+    lifelong_rng  'build' (default): the lifelong (on_target='restart') target draw uses the build's counter-based stream;
+                  'numpy'      : per-agent numpy generators set up as upstream `PogemaLifeLong._initialize_grid` does
+                                 (recalled, conf. medium): main = default_rng(seed_env); seeds = main.integers(2^31-1,
+                                 size=A); generator[a] = default_rng(seeds[a]); target = component[generator[a]
+                                 .integers(0, len(component))]; re-created at every reset.  seed_env = GridConfig.seed +
+                                 global env index.  The numpy arithmetic is bit-exact (pogema_amd/nprng.py); the ORDER of
+                                 a component's cells stays build-defined (row-major).
+
 `PGX_SEMANTICS="soft_vertex=all_stay,coop_reward=per_agent"` overrides the defaults process-wide (one-step pinning
 of a whole test run against fixtures from the real package).
 """
@@ -25,6 +33,7 @@ from __future__ import annotations
 import os
 from dataclasses import dataclass
 
+LIFELONG_RNG = ("build", "numpy")
 SOFT_VERTEX = ("lowest_index", "all_stay")
 COOP_REWARD = ("all_solved", "per_agent")
 BAD_ACTION = ("noop", "flag")
@@ -35,9 +44,11 @@ class Semantics:
     soft_vertex: str = "lowest_index"
     coop_reward: str = "all_solved"
     bad_action: str = "noop"
+    lifelong_rng: str = "build"
 
     def __post_init__(self):
-        for name, allowed in (("soft_vertex", SOFT_VERTEX), ("coop_reward", COOP_REWARD), ("bad_action", BAD_ACTION)):
+        for name, allowed in (("soft_vertex", SOFT_VERTEX), ("coop_reward", COOP_REWARD), ("bad_action", BAD_ACTION),
+                              ("lifelong_rng", LIFELONG_RNG)):
             if getattr(self, name) not in allowed:
                 raise ValueError(f"Semantics.{name} must be one of {allowed}, got {getattr(self, name)!r}")
 
@@ -50,11 +61,12 @@ class Semantics:
             if "=" not in item:
                 raise ValueError(f"PGX_SEMANTICS entry {item!r} is not key=value")
             k, v = item.split("=", 1)
-            if k not in ("soft_vertex", "coop_reward", "bad_action"):
+            if k not in ("soft_vertex", "coop_reward", "bad_action", "lifelong_rng"):
                 raise ValueError(f"PGX_SEMANTICS: unknown switch {k!r}")
             kw[k] = v
         return cls(**kw)
 
     def oracle_kwargs(self) -> dict:
         """The same switches under the oracles' parameter names (tests only)."""
-        return {"soft_vertex_rule": self.soft_vertex, "coop_reward": self.coop_reward, "bad_action": self.bad_action}
+        return {"soft_vertex_rule": self.soft_vertex, "coop_reward": self.coop_reward, "bad_action": self.bad_action,
+                "lifelong_rng": self.lifelong_rng}

@@ -99,7 +99,8 @@ class VecPogema:
             env_index_base=self.env_index_base, random_outside=0 if gc.empty_outside else 1,
             outside_density=float(gc.density), soft_vertex_rule=_lib.SOFT_VERTEX_RULES[self.semantics.soft_vertex],
             coop_reward=_lib.COOP_REWARDS[self.semantics.coop_reward],
-            bad_action=_lib.BAD_ACTIONS[self.semantics.bad_action])
+            bad_action=_lib.BAD_ACTIONS[self.semantics.bad_action],
+            lifelong_rng=_lib.LIFELONG_RNGS[self.semantics.lifelong_rng])
         self._handle = C.c_void_p()
         _lib.check(self._lib.pgx_create(C.byref(cfg), self.device_index, C.byref(self._handle)))
         self._bufs = None

@@ -270,3 +270,42 @@ def test_bad_actions_noop_and_flag():
         env.step(torch.from_numpy(bad[1]).cuda())
     env.step(torch.from_numpy(good[2]).cuda())  # the counter was cleared by the raise
     env.close()
+
+
+@pytest.mark.parametrize("geom", [g for g in GEOMETRIES if g[0] in ("baseline_cfg1", "dense_small", "full_wave", "two_slots")],
+                         ids=lambda g: g[0])
+@pytest.mark.parametrize("auto_reset", [False, True])
+def test_lifelong_numpy_stream(geom, auto_reset):
+    """Semantics(lifelong_rng='numpy'): the lifelong target draw follows per-agent numpy generators set up like upstream
+    `PogemaLifeLong._initialize_grid` (recalled).  The oracle uses numpy ITSELF (np.random.default_rng, .integers,
+    .choice); the engine its own SeedSequence / PCG64 / Lemire arithmetic on the device -- targets, rewards and the
+    target planes must agree for the whole rollout, through auto-resets (generators re-created)."""
+    from pogema_amd import Semantics
+    name, B, H, Wd, A, r, density, T, max_steps = geom
+    seed = zlib.crc32(f"npll/{name}".encode()) % (2 ** 31)
+    obstacles, agents, targets = generate_instances(B, H, Wd, A, density, seed)
+    # goal-seeking actions: agents must actually reach targets (several times) for the stream to be consumed
+    sem = Semantics(lifelong_rng="numpy")
+    kw = dict(obs_radius=r, collision_system="soft", on_target="restart", max_episode_steps=max_steps, auto_reset=auto_reset,
+              seed=2025, env_index_base=7, semantics=sem)
+    rng = np.random.default_rng(seed)
+    from oracle.pogema_oracle import PogemaOracle
+    envs = [PogemaOracle(obstacles[b], agents[b], targets[b], obs_radius=r, collision_system="soft", on_target="restart",
+                         max_episode_steps=max_steps, auto_reset=auto_reset, seed=2025, env_index=7 + b,
+                         lifelong_rng="numpy") for b in range(B)]
+    T = 3 * T
+    actions = np.zeros((T, B, A), np.int64)
+    for t in range(T):  # roll the oracle once to script goal-seeking actions from its states
+        for b, e in enumerate(envs):
+            st = e.get_state()
+            d = st["targets_xy"].astype(np.int64) - st["agents_xy"].astype(np.int64)
+            greedy = np.where(np.abs(d[:, 0]) >= np.abs(d[:, 1]), np.where(d[:, 0] < 0, 1, 2), np.where(d[:, 1] < 0, 3, 4))
+            greedy = np.where((d == 0).all(axis=1), 0, greedy)
+            actions[t, b] = np.where(rng.random(A) < 0.3, rng.integers(0, 5, A), greedy)
+            e.step(actions[t, b])
+    ref = oracle_rollout(obstacles, agents, targets, actions, **kw)
+    assert ref["rewards"].sum() >= B, "targets must be reached for the numpy stream to be exercised"
+    got = engine_rollout(obstacles, agents, targets, actions, **kw)
+    assert_rollouts_equal(ref, got, f"numpy lifelong/{name}/auto_reset={auto_reset}")
+    base = oracle_rollout(obstacles, agents, targets, actions, **{**kw, "semantics": None})
+    assert not np.array_equal(base["targets_xy"], ref["targets_xy"]), "the numpy stream differs from the build's stream"

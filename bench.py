@@ -228,7 +228,7 @@ class EngineStep:
             return (f"2 alternating buffers from the engine's zone-aware pool: halves in two HBM zones = {pl['spread']} "
                     f"(probe stream {pl['same_zone_us']:.1f} us same-zone -> {pl['final_us']:.1f} us as placed, "
                     f"{pl['candidates']} candidates, {pl['spacer_gib']:.0f} GiB of temporary spacers; plain store stream "
-                    f"into buffer 0: {pl['buffer_gbs']:.0f} GB/s)")
+                    f"into the slowest buffer: {pl['buffer_gbs']:.0f} GB/s)")
         return "2 alternating buffers as torch's allocator returned them (no zone placement)"
 
     def close(self):
@@ -364,17 +364,7 @@ def main(argv=None):
             kernel.append(ev0.elapsed_time(ev1) / args.steps if not args.stub else own / args.steps * 1e3)
         return walls, kernel
 
-    # the default-allocator placement first, in a fresh address space (before the probe's candidates exist)
     default_ms = None
-    if not args.stub and not args.no_default_placement and world == 1:
-        plain = EngineStep(args, rank, device, batch, env_base, size, agents, r, placement_probe=False)
-        plain.run(max(args.warmup, 4))
-        _, k = timed_windows(plain, 1)
-        default_ms = k[0]
-        plain.close()
-        del plain
-        torch.cuda.empty_cache()
-
     step = StubStep(rank) if args.stub else EngineStep(args, rank, device, batch, env_base, size, agents, r)
     warm = args.warmup if args.graph <= 0 else -(-args.warmup // args.graph) * args.graph
     if warm:
@@ -388,6 +378,17 @@ def main(argv=None):
         parts = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(parts, t)
         per_rank_kernel = [float(p.item()) for p in parts]
+
+    # the same workload into buffers as torch's allocator hands them out (no zone placement), AFTER the main measurement:
+    # allocating and freeing them first would leave holes that the zone walk of the main run falls into
+    if not args.stub and not args.no_default_placement and world == 1:
+        plain = EngineStep(args, rank, device, batch, env_base, size, agents, r, placement_probe=False)
+        plain.run(max(args.warmup, 4))
+        _, k = timed_windows(plain, 1)
+        default_ms = k[0]
+        plain.close()
+        del plain
+        torch.cuda.empty_cache()
 
     if rank == 0:
         n_agent_steps = total_envs * agents * args.steps

@@ -195,9 +195,9 @@ void find_other_zone(int device, size_t budget, std::vector<Range>& held, pgx_bu
     float t_same = 0.f;
     if (probe_us(ref, held.back().va, PROBE_HALF, &t_same) != hipSuccess) return;
     info.same_zone_us = info.final_us = t_same;
-    // A one-zone stream sustains 5.5-6.0 TB/s on every device measured, a two-zone stream 6.7-7.9 TB/s: a pair that
-    // already exceeds 6.3 TB/s straddles a zone boundary as it is -- the allocator stands in the other zone already.
-    const float t_spread_abs = (float)(2.0 * (double)PROBE_HALF / 6.3e12 * 1e6);
+    // A one-zone stream sustains 5.4-6.2 TB/s on the devices measured, a 1:1 two-zone stream 6.7-7.0 TB/s: a pair that
+    // already reaches 6.6 TB/s straddles a zone boundary as it is -- the allocator stands in the other zone already.
+    const float t_spread_abs = (float)(2.0 * (double)PROBE_HALF / 6.6e12 * 1e6);
     if (t_same <= t_spread_abs) {
         *found = true;
         return;
@@ -275,9 +275,10 @@ int pgx_buffers_create(int device, size_t bytes, int count, double max_spacer_gi
         e = map_part(device, p->buf[i].va, p->first, p->buf[i].parts[0]);
         if (e != hipSuccess) return bail(code_of(e), "hipMemCreate/hipMemMap (first half)", e);
     }
-    // 2. walk the allocator into another zone (worth it for streams that are bandwidth-bound: buffers >= 16 MiB)
+    // 2. walk the allocator into another zone.  Buffers below 256 MiB are left alone: a repeated stream of that size is
+    //    absorbed by the Infinity Cache and too short to be bandwidth-bound (configs[3], 190 MB: +-2 % either way).
     bool found = false;
-    if (p->second && total >= ((size_t)16 << 20) && max_spacer_gib > 0.0) {
+    if (p->second && total >= ((size_t)256 << 20) && max_spacer_gib > 0.0) {
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
         const size_t need = (size_t)count * p->second + 20 * PROBE_HALF + 4 * GiB;
@@ -297,10 +298,15 @@ int pgx_buffers_create(int device, size_t bytes, int count, double max_spacer_gi
     }
     for (Range& s : held) s.release();
     p->info.spread = found ? 1 : 0;
-    if (p->second && total >= ((size_t)256 << 20)) {
-        float t = 0.f;
-        if (probe_us(p->buf[0].va, (char*)p->buf[0].va + p->first, p->second, &t) == hipSuccess && t > 0.f)
-            p->info.buffer_gbs = (float)(2.0 * (double)p->second / ((double)t * 1e-6) / 1e9);
+    if (p->second && total >= ((size_t)256 << 20)) {  // what the buffers themselves sustain (slowest one)
+        double worst = 0.0;
+        for (int i = 0; i < count; ++i) {
+            float t = 0.f;
+            if (probe_us(p->buf[i].va, (char*)p->buf[i].va + p->first, p->second, &t) != hipSuccess || t <= 0.f) continue;
+            const double gbs = 2.0 * (double)p->second / ((double)t * 1e-6) / 1e9;
+            if (worst == 0.0 || gbs < worst) worst = gbs;
+        }
+        p->info.buffer_gbs = (float)worst;
     }
     (void)hipGetLastError();
     *out = p;

@@ -316,9 +316,9 @@ class VecPogema:
     # another zone ~6.9 TB/s (DESIGN.md "placement", profiles/r2/placement_*.txt).  A plain allocation is physically
     # compact -- one zone, unless it straddles a boundary by luck (round 1 searched for such lucky buffers by timing up
     # to 64 candidates).  The engine's buffer pool (pgx_buffers_create) REQUESTS the placement instead: each buffer is
-    # one virtual range whose second half is backed by another zone, verified by timing.  Buffers below 64 MB are
-    # latency-bound and come from torch's allocator as they are.
-    PLACEMENT_MIN_BYTES = 64 << 20
+    # one virtual range whose second half is backed by another zone, verified by timing.  Buffers below 256 MiB (a
+    # repeated stream of that size is absorbed by the Infinity Cache; configs[3]: +-2 %) come from torch's allocator.
+    PLACEMENT_MIN_BYTES = 256 << 20
 
     def _pick_obs_buffers(self):
         obs_bytes = int(np.prod(self.obs_shape)) * (4 if self.obs_dtype == torch.float32 else 1)

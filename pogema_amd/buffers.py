@@ -45,7 +45,9 @@ class ZoneBuffers:
     """`count` buffers of `shape`/`dtype` on `device`, each spread over two HBM zones when reachable.
 
     max_spacer_gib: memory the search may hold temporarily while it walks the allocator into another zone (released
-    before the constructor returns); default PGX_ZONE_SPACER_GIB or 128; 0 disables the search."""
+    before the constructor returns; the engine additionally keeps 10 % of the free memory untouched).  The next zone can
+    be 40 ... > 128 GiB away from where the allocator stands (profiles/r2/placement_walk_scan.txt), so the default lets
+    the walk use all free memory: PGX_ZONE_SPACER_GIB or 272; 0 disables the search.  PGX_DEBUG=1 traces the walk."""
 
     def __init__(self, shape, dtype, device, count=2, max_spacer_gib=None):
         if dtype not in _TYPESTR:
@@ -53,7 +55,7 @@ class ZoneBuffers:
         dev = torch.device(device)
         index = dev.index if dev.index is not None else torch.cuda.current_device()
         if max_spacer_gib is None:
-            max_spacer_gib = float(os.environ.get("PGX_ZONE_SPACER_GIB", "128"))
+            max_spacer_gib = float(os.environ.get("PGX_ZONE_SPACER_GIB", "272"))
         lib = _lib.load()
         nbytes = int(np.prod(shape)) * (4 if dtype == torch.float32 else 1)
         handle = C.c_void_p()

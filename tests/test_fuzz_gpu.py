@@ -28,7 +28,9 @@ def _random_case(rng):
                 on_target=str(rng.choice(ON_TARGET)), max_steps=int(rng.integers(1, 12)),
                 auto_reset=bool(rng.integers(0, 2)), T=int(rng.integers(3, 20)),
                 action_dtype=str(rng.choice(["int8", "int32", "int64"])), u8=bool(rng.integers(0, 2)),
-                seed=int(rng.integers(0, 2 ** 31)), base=int(rng.integers(0, 1000)))
+                seed=int(rng.integers(0, 2 ** 31)), base=int(rng.integers(0, 1000)),
+                soft_vertex=str(rng.choice(["lowest_index", "all_stay"])), coop_reward=str(rng.choice(["all_solved", "per_agent"])),
+                bad=bool(rng.integers(0, 4) == 0))
 
 
 def _instances(c):
@@ -55,10 +57,14 @@ def test_random_configurations(chunk):
         st, o, a, t = _instances(c)
         if st != 0:
             continue  # unplaceable draw (tiny map, many agents): not what this test is about
+        from pogema_amd import Semantics
         actions = random_actions(c["T"], c["B"], c["A"], c["seed"] % 1000 + 1)
+        if c["bad"]:  # a quarter of the cases carry out-of-range actions (noops under the default semantics)
+            junk = rng.random(actions.shape) < 0.1
+            actions = np.where(junk, rng.choice([-3, 5, 9, 100], size=actions.shape), actions)
         kw = dict(obs_radius=c["r"], collision_system=c["collision"], on_target=c["on_target"],
                   max_episode_steps=c["max_steps"], auto_reset=c["auto_reset"], seed=c["seed"] % 977,
-                  env_index_base=c["base"])
+                  env_index_base=c["base"], semantics=Semantics(soft_vertex=c["soft_vertex"], coop_reward=c["coop_reward"]))
         ref = c_oracle_rollout(o, a, t, actions, nthreads=4, **kw)
         got = engine_rollout(o, a, t, actions, action_dtype=c["action_dtype"],
                              obs_dtype=torch.uint8 if c["u8"] else None, **kw)

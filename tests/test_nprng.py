@@ -71,3 +71,19 @@ def test_bad_arguments():
         np_streams_host([1], "integers", 4, n=0)
     with pytest.raises(PgxError):
         np_streams_host([1], "binomial1", 4, p=1.5)
+
+
+from hypothesis import given, settings, strategies as st  # noqa: E402
+
+
+@settings(max_examples=150, deadline=None)
+@given(seed=st.integers(0, 2 ** 64 - 1), n=st.one_of(st.integers(1, 2 ** 16), st.integers(1, 2 ** 63 - 1), st.sampled_from([2 ** 32 - 1, 2 ** 32, 2 ** 32 + 1])),
+       p=st.floats(0.0, 1.0), draws=st.integers(1, 64))
+def test_primitives_property(seed, n, p, draws):
+    """Arbitrary seeds / bounds / probabilities: every primitive equals numpy's Generator draw for draw."""
+    assert np.array_equal(np_streams_host([seed], "integers", draws, n=n)[0],
+                          np.random.default_rng(seed).integers(0, n, size=draws))
+    assert np.array_equal(np_streams_host([seed], "binomial1", draws, p=p)[0],
+                          np.random.default_rng(seed).binomial(1, p, size=draws))
+    assert np.array_equal(np_streams_host([seed], "permutation", draws)[0], np.random.default_rng(seed).permutation(draws))
+    assert np.array_equal(np_streams_host([seed], "random", draws)[0], np.random.default_rng(seed).random(draws))

@@ -15,8 +15,8 @@ ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc 
     python -m pytest tests/test_oracle.py tests/test_generator.py -q -x
 cp /tmp/libpogema_oracle_backup.so oracle/libpogema_oracle.so
 (cd pogema_amd/csrc && /opt/rocm/bin/hipcc -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -fsanitize=address \
-    -fno-gpu-sanitize -shared-libsan -x hip pgx_kernels.hip pgx_reset.hip pgx_api.cpp -shared \
+    -fno-gpu-sanitize -shared-libsan -x hip pgx_kernels.hip pgx_reset.hip pgx_buffers.hip pgx_nprng.hip pgx_api.cpp -shared \
     -o /tmp/libpogema_amd_asan.so -pthread)
 ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 PGX_LIB=/tmp/libpogema_amd_asan.so \
     LD_PRELOAD=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1) \
-    python -m pytest tests/test_generator.py tests/test_abi.py tests/test_oracle.py -q -x
+    python -m pytest tests/test_generator.py tests/test_abi.py tests/test_oracle.py tests/test_nprng.py -q -x

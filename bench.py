@@ -185,7 +185,8 @@ class EngineStep:
                         collision_system=args.collision, on_target=args.on_target,
                         max_episode_steps=args.max_episode_steps)
         self.env = VecPogema(gc, batch=batch, device=device, env_index_base=env_base,
-                             auto_reset=True if args.auto_reset == "restore" else "regenerate", reuse_buffers=True,
+                             auto_reset=True if args.auto_reset == "restore" else "regenerate",
+                             reuse_buffers=True if args.buffers == 2 else "single",
                              obs_dtype=torch.float32 if args.obs_dtype == "float32" else torch.uint8,
                              placement_probe=placement_probe)
         self.env.reset(seed=0)
@@ -194,6 +195,7 @@ class EngineStep:
         gen.manual_seed(1 + rank)
         self.pool = [torch.randint(0, 5, (batch, agents), generator=gen, device=device).to(tdt) for _ in range(32)]
         self.no_obs = args.no_obs
+        self.nbuf = args.buffers
         self.graph = None
         self.graph_len = 0
         self.i = 0
@@ -225,11 +227,11 @@ class EngineStep:
     def describe_buffers(self):
         pl = getattr(self.env, "placement", None) or {}
         if pl.get("method", "").startswith("pgx_buffers"):
-            return (f"2 alternating buffers from the engine's zone-aware pool: halves in two HBM zones = {pl['spread']} "
+            return (f"{self.nbuf} alternating buffers from the engine's zone-aware pool: halves in two HBM zones = {pl['spread']} "
                     f"(probe stream {pl['same_zone_us']:.1f} us same-zone -> {pl['final_us']:.1f} us as placed, "
                     f"{pl['candidates']} candidates, {pl['spacer_gib']:.0f} GiB of temporary spacers; plain store stream "
                     f"into the slowest buffer: {pl['buffer_gbs']:.0f} GB/s)")
-        return "2 alternating buffers as torch's allocator returned them (no zone placement)"
+        return f"{self.nbuf} output buffer(s) as torch's allocator returned them (no zone placement)"
 
     def close(self):
         self.env.close()
@@ -275,6 +277,8 @@ def main(argv=None):
     ap.add_argument("--auto-reset", default="restore", choices=["restore", "regenerate"],
                     help="restore = finished envs return to their initial state inside the step kernel (headline); "
                          "regenerate = they get a fresh random instance on the device (pgx_regenerate)")
+    ap.add_argument("--buffers", type=int, default=2, choices=[1, 2],
+                    help="output buffer sets: 2 alternating (default; step t's tensors survive step t+1) or 1 rewritten in place")
     ap.add_argument("--graph", type=int, default=0, help="capture this many steps in one HIP graph and replay it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-default-placement", action="store_true",
@@ -425,7 +429,7 @@ def main(argv=None):
                        "sharding": f"batch-sharded x{world}, no collective",
                        "launch": f"hipGraph of {args.graph} steps" if args.graph > 0 else "one pgx_step launch per step",
                        "obs_buffers": step.describe_buffers()},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm" if (args.buffers == 2 or alg_bytes > (200 << 20)) else "hbm (output tensor rewritten in place: largely Infinity-Cache resident)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "pgx::step_kernel", "kernel_ms": kernel_ms, "kernel_ms_per_rank": per_rank_kernel,
                          "kernel_ms_windows": kernel,

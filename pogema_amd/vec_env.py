@@ -42,7 +42,7 @@ class VecPogema:
     of fresh allocations whose placement in HBM is arbitrary (the same kernel runs 140..153 us per step depending on
     where its output buffer lives).  ALIASING: with `reuse_buffers=True` every tensor returned by step t (obs, rewards,
     terminated, truncated, infos['is_active']) is overwritten by step t+2 -- consume or copy it before then, or hand
-    step() your own buffers with `out=`.
+    step() your own buffers with `out=`.  `reuse_buffers="single"`: one set only, overwritten by EVERY step.
 
     `semantics`: switches for the three low-confidence recollections of the reference (pogema_amd/semantics.py).
     Seeds: `reset(seed)` selects the instances (maps, starts, targets); the lifelong target stream and the
@@ -81,6 +81,12 @@ class VecPogema:
                                 or gc.possible_agents_xy is not None):
             raise NotImplementedError("auto_reset='regenerate' needs random instances and observation_type='default'")
         self.auto_reset = bool(auto_reset)
+        # True: two alternating output sets; "single": ONE set, overwritten by every step (for callers that consume the
+        # observation before the next step: a tensor of <= ~200 MB rewritten in place stays largely inside the 256 MiB
+        # Infinity Cache -- configs[3]: bare stream 28 instead of 32 us)
+        if reuse_buffers not in (False, True, "single"):
+            raise ValueError("reuse_buffers must be False, True or 'single'")
+        self.single_buffer = reuse_buffers == "single"
         self.reuse_buffers = bool(reuse_buffers)
         self.semantics = semantics if semantics is not None else Semantics.from_env()
         # placement probe of the double-buffered observation tensors (reuse_buffers=True); PGX_PLACEMENT=0 disables
@@ -339,7 +345,7 @@ class VecPogema:
         if self._bufs is None:
             obs_a, obs_b = self._pick_obs_buffers()
             self._bufs = [(obs_a,) + self._alloc_outputs(False)[1:], (obs_b,) + self._alloc_outputs(False)[1:]]
-        self._buf_i ^= 1
+        self._buf_i = 0 if self.single_buffer else self._buf_i ^ 1
         return self._bufs[self._buf_i]
 
     def observe(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:

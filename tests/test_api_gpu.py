@@ -367,3 +367,26 @@ def test_two_handles_share_a_kernel_with_different_lds_needs():
     torch.cuda.synchronize()
     big.close()
     small.close()
+
+
+def test_single_output_buffer_mode():
+    """reuse_buffers='single': every step writes the same output set (valid until the next step); results identical."""
+    import torch
+    from pogema_amd import GridConfig, VecPogema
+    gc = GridConfig(size=12, num_agents=7, obs_radius=3, density=0.2, seed=4, collision_system="soft", max_episode_steps=6)
+    a = VecPogema(gc, batch=9, auto_reset=True)
+    b = VecPogema(gc, batch=9, auto_reset=True, reuse_buffers="single")
+    a.reset(seed=4)
+    b.reset(seed=4)
+    ptrs = set()
+    for t in range(10):
+        acts = torch.randint(0, 5, (9, 7), device="cuda", dtype=torch.int8)
+        oa, ra, ta, tra, _ = a.step(acts)
+        ob, rb, tb, trb, _ = b.step(acts)
+        assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(ta, tb) and torch.equal(tra, trb)
+        ptrs.add((ob.data_ptr(), rb.data_ptr()))
+    assert len(ptrs) == 1
+    with pytest.raises(ValueError):
+        VecPogema(gc, batch=2, reuse_buffers="double")
+    a.close()
+    b.close()

@@ -328,11 +328,12 @@ class VecPogema:
 
     def _pick_obs_buffers(self):
         obs_bytes = int(np.prod(self.obs_shape)) * (4 if self.obs_dtype == torch.float32 else 1)
+        n = 1 if self.single_buffer else 2
         if not self.placement_probe or obs_bytes < self.PLACEMENT_MIN_BYTES:
             self.placement = {"spread": False, "method": "torch allocator"}
-            return [torch.empty(self.obs_shape, dtype=self.obs_dtype, device=self.device) for _ in range(2)]
+            return [torch.empty(self.obs_shape, dtype=self.obs_dtype, device=self.device) for _ in range(n)]
         from .buffers import ZoneBuffers
-        pool = ZoneBuffers(self.obs_shape, self.obs_dtype, self.device, count=2)
+        pool = ZoneBuffers(self.obs_shape, self.obs_dtype, self.device, count=n)
         self.placement = dict(pool.info, method="pgx_buffers (two HBM zones per buffer)")
         return pool.tensors
 
@@ -343,8 +344,7 @@ class VecPogema:
         if not self.reuse_buffers:
             return self._alloc_outputs()
         if self._bufs is None:
-            obs_a, obs_b = self._pick_obs_buffers()
-            self._bufs = [(obs_a,) + self._alloc_outputs(False)[1:], (obs_b,) + self._alloc_outputs(False)[1:]]
+            self._bufs = [(obs,) + self._alloc_outputs(False)[1:] for obs in self._pick_obs_buffers()]
         self._buf_i = 0 if self.single_buffer else self._buf_i ^ 1
         return self._bufs[self._buf_i]
 

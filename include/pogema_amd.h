@@ -286,6 +286,21 @@ int pgx_np_streams(const uint64_t* seeds, int64_t streams, int32_t op, uint64_t 
                    void* stream);
 int pgx_np_streams_host(const uint64_t* seeds, int64_t streams, int32_t op, uint64_t n, double p, int64_t draws, void* out);
 
+/* Instances drawn the way upstream draws them (pogema/generator.py `generate_obstacles` +
+ * `generate_positions_and_targets_fast` / `placing`, RECALLED, conf. medium): obstacles =
+ * default_rng(seed).binomial(1, density, (H, W)); the free cells, row-major, shuffled with default_rng(seed); every cell
+ * linked to the next cell of its 4-connected component in that order; walking the order, a linked cell becomes a start
+ * and its link the target; the first `num_agents` pairs are the agents.  Env b uses seeds[b].  With the recollection
+ * right these are upstream's instances for that seed; the numpy arithmetic itself is exact.  Outputs are in the format
+ * pgx_reset_from_state takes.  `given_map` (u8 [H*W], non-zero = obstacle; may be NULL) replaces the obstacle draw for
+ * every env, as GridConfig.map does upstream.  status[b] = 1 when env b has fewer than `num_agents` pairs (upstream: OverflowError).
+ *   pgx_np_generate       device pointers; one GPU thread per env; scratch u32 [batch * 4 * H * W]; asynchronous
+ *   pgx_np_generate_host  host pointers; scratch u32 [4 * H * W] */
+int pgx_np_generate(const uint64_t* seeds, int32_t batch, int32_t height, int32_t width, int32_t num_agents, double density,
+                    const uint8_t* given_map, uint8_t* obstacles, int32_t* agent_xy, int32_t* target_xy, uint32_t* scratch, int32_t* status, void* stream);
+int pgx_np_generate_host(const uint64_t* seeds, int32_t batch, int32_t height, int32_t width, int32_t num_agents, double density,
+                         const uint8_t* given_map, uint8_t* obstacles, int32_t* agent_xy, int32_t* target_xy, uint32_t* scratch, int32_t* status);
+
 /* ---- state export ------------------------------------------------------------------------------- */
 /* Replaces `Grid.get_agents_xy` / `get_targets_xy` / `is_active` / the occupancy array (`positions`).
  * Any pointer may be NULL.  All device pointers.

@@ -147,3 +147,37 @@ def place_from_possible(seed, env, possible_agents_xy, possible_targets_xy, num_
                 chosen.append(i)
         out.append(np.array([cells[i] for i in chosen], np.int32).reshape(-1, 2))
     return out[0], out[1]
+
+
+def generate_instance_numpy(seed, height, width, num_agents, density, given_map=None):
+    """Upstream's generator as RECALLED (pogema/generator.py `generate_obstacles`, `generate_positions_and_targets_fast`,
+    `placing`; conf. medium -- the source is not mounted), written with numpy ITSELF: the checker of
+    pgx_np_generate / pgx_np_generate_host.  Raises OverflowError when fewer than `num_agents` pairs exist."""
+    from .pogema_oracle import label_components
+    if given_map is not None:
+        obstacles = (np.asarray(given_map) != 0).astype(np.int64)
+    else:
+        obstacles = np.random.default_rng(seed).binomial(1, density, (height, width))
+    labels, _ = label_components(obstacles)
+    order = [(x, y) for x in range(height) for y in range(width) if obstacles[x, y] == 0]
+    np.random.default_rng(seed).shuffle(order)
+    link_to_next = [-1] * len(order)
+    colors = {}
+    for index in range(len(order)):
+        reversed_index = len(order) - index - 1
+        color = int(labels[order[reversed_index]])
+        link_to_next[reversed_index] = colors.get(color, -1)
+        colors[color] = reversed_index
+    positions_xy, finishes_xy = [], []
+    for index in range(len(order)):
+        next_index = link_to_next[index]
+        if next_index == -1:
+            continue
+        positions_xy.append(order[index])
+        finishes_xy.append(order[next_index])
+        link_to_next[next_index] = -1
+        if len(finishes_xy) >= num_agents:
+            break
+    if len(finishes_xy) < num_agents:
+        raise OverflowError(f"only {len(finishes_xy)} of {num_agents} start/target pairs can be placed")
+    return obstacles.astype(np.uint8), np.array(positions_xy, np.int32), np.array(finishes_xy, np.int32)

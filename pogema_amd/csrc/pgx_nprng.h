@@ -208,3 +208,74 @@ PGX_NP_HD int64_t binomial1(Pcg64& g, double p, double qn) {
 }
 
 }  // namespace pgxnp
+
+// ---- instance generation the way upstream does it (recalled) -----------------------------------------------------------
+// Upstream pogema/generator.py, as recalled (conf. medium -- the source is not mounted):
+//   generate_obstacles:                    obstacles = default_rng(seed).binomial(1, density, (H, W))
+//   generate_positions_and_targets_fast:   order = free cells, row-major;  default_rng(seed).shuffle(order);
+//   placing:                               every cell is linked to the NEXT cell of its 4-connected component in `order`;
+//                                          walking `order`, a cell with a link becomes a start, the linked cell its target
+//                                          (and loses its own link); the first `num_agents` such pairs are the agents.
+// One call builds one instance; `scratch` holds 4 * H * W words.  Returns 0, or 1 when fewer than `num_agents` pairs
+// exist (upstream: OverflowError).  With `given_map` (H*W bytes, non-zero = obstacle) the obstacles are taken from it and
+// only the positions are drawn (upstream with GridConfig.map set).  Host and device run the same code; the numpy arithmetic is bit-exact
+// (tests/test_nprng.py), so with the recollection right this reproduces upstream's instances for a given seed.
+namespace pgxnp {
+
+PGX_NP_HD int generate_instance(uint64_t seed, int H, int W, int num_agents, double density, double qn,
+                                const uint8_t* given_map, uint8_t* map,
+                                int32_t* agent_xy, int32_t* target_xy, uint32_t* scratch) {
+    const int cells = H * W;
+    uint32_t* stack = scratch;               // flood-fill stack, later `colors`
+    uint32_t* label = scratch + cells;
+    uint32_t* order = scratch + 2 * cells;
+    uint32_t* link = scratch + 3 * cells;
+    constexpr uint32_t NONE = 0xFFFFFFFFu, OBST = 0xFFFFFFFEu;
+    Pcg64 g = default_rng(seed);
+    for (int c = 0; c < cells; ++c) {
+        map[c] = given_map ? (uint8_t)(given_map[c] != 0) : (uint8_t)binomial1(g, density, qn);
+        label[c] = map[c] ? OBST : NONE;
+    }
+    uint32_t ncomp = 0;
+    for (int s = 0; s < cells; ++s) {
+        if (label[s] != NONE) continue;
+        int sp = 0;
+        stack[sp++] = (uint32_t)s;
+        label[s] = ncomp;
+        while (sp) {
+            const int c = (int)stack[--sp];
+            const int x = c / W, y = c - x * W;
+            if (x > 0 && label[c - W] == NONE) { label[c - W] = ncomp; stack[sp++] = (uint32_t)(c - W); }
+            if (x + 1 < H && label[c + W] == NONE) { label[c + W] = ncomp; stack[sp++] = (uint32_t)(c + W); }
+            if (y > 0 && label[c - 1] == NONE) { label[c - 1] = ncomp; stack[sp++] = (uint32_t)(c - 1); }
+            if (y + 1 < W && label[c + 1] == NONE) { label[c + 1] = ncomp; stack[sp++] = (uint32_t)(c + 1); }
+        }
+        ++ncomp;
+    }
+    int n = 0;
+    for (int c = 0; c < cells; ++c)
+        if (!map[c]) order[n++] = (uint32_t)c;
+    Pcg64 g2 = default_rng(seed);
+    shuffle(g2, order, (int64_t)n);
+    uint32_t* colors = stack;
+    for (uint32_t k = 0; k < ncomp; ++k) colors[k] = NONE;
+    for (int idx = n - 1; idx >= 0; --idx) {
+        const uint32_t color = label[order[idx]];
+        link[idx] = colors[color];
+        colors[color] = (uint32_t)idx;
+    }
+    int placed = 0;
+    for (int idx = 0; idx < n && placed < num_agents; ++idx) {
+        const uint32_t nx = link[idx];
+        if (nx == NONE) continue;
+        agent_xy[2 * placed] = (int32_t)(order[idx] / (uint32_t)W);
+        agent_xy[2 * placed + 1] = (int32_t)(order[idx] % (uint32_t)W);
+        target_xy[2 * placed] = (int32_t)(order[nx] / (uint32_t)W);
+        target_xy[2 * placed + 1] = (int32_t)(order[nx] % (uint32_t)W);
+        link[nx] = NONE;
+        ++placed;
+    }
+    return placed >= num_agents ? 0 : 1;
+}
+
+}  // namespace pgxnp

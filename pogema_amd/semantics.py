@@ -25,6 +25,14 @@ matrix -- so that pinning against the real package is a flip here, not a kernel 
                                  global env index.  The numpy arithmetic is bit-exact (pogema_amd/nprng.py); the ORDER of
                                  a component's cells stays build-defined (row-major).
 
+    generator_rng 'build' (default): random instances come from the build's counter-based generator (connectivity-checked
+                                 obstacles, rejection-sampled starts/targets; docs/SPEC.md);
+                  'numpy'      : instances are drawn as upstream draws them (pogema/generator.py, recalled, conf. medium):
+                                 obstacles = default_rng(seed_env).binomial(1, density, (H, W)); free cells shuffled by a
+                                 fresh default_rng(seed_env); starts/targets paired along each component in that order
+                                 (`placing`).  One GPU thread per env (pgx_np_generate); OverflowError when an env
+                                 cannot hold `num_agents` pairs.  A host-only switch: the step kernel never sees it.
+
 `PGX_SEMANTICS="soft_vertex=all_stay,coop_reward=per_agent"` overrides the defaults process-wide (one-step pinning
 of a whole test run against fixtures from the real package).
 """
@@ -37,6 +45,7 @@ LIFELONG_RNG = ("build", "numpy")
 SOFT_VERTEX = ("lowest_index", "all_stay")
 COOP_REWARD = ("all_solved", "per_agent")
 BAD_ACTION = ("noop", "flag")
+GENERATOR_RNG = ("build", "numpy")
 
 
 @dataclass(frozen=True)
@@ -45,10 +54,11 @@ class Semantics:
     coop_reward: str = "all_solved"
     bad_action: str = "noop"
     lifelong_rng: str = "build"
+    generator_rng: str = "build"
 
     def __post_init__(self):
         for name, allowed in (("soft_vertex", SOFT_VERTEX), ("coop_reward", COOP_REWARD), ("bad_action", BAD_ACTION),
-                              ("lifelong_rng", LIFELONG_RNG)):
+                              ("lifelong_rng", LIFELONG_RNG), ("generator_rng", GENERATOR_RNG)):
             if getattr(self, name) not in allowed:
                 raise ValueError(f"Semantics.{name} must be one of {allowed}, got {getattr(self, name)!r}")
 
@@ -61,7 +71,7 @@ class Semantics:
             if "=" not in item:
                 raise ValueError(f"PGX_SEMANTICS entry {item!r} is not key=value")
             k, v = item.split("=", 1)
-            if k not in ("soft_vertex", "coop_reward", "bad_action", "lifelong_rng"):
+            if k not in ("soft_vertex", "coop_reward", "bad_action", "lifelong_rng", "generator_rng"):
                 raise ValueError(f"PGX_SEMANTICS: unknown switch {k!r}")
             kw[k] = v
         return cls(**kw)

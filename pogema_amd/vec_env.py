@@ -80,6 +80,9 @@ class VecPogema:
         if self.regenerate and (gc.observation_type != "default" or (gc.map is not None and gc.agents_xy is not None)
                                 or gc.possible_agents_xy is not None):
             raise NotImplementedError("auto_reset='regenerate' needs random instances and observation_type='default'")
+        if self.regenerate and (semantics if semantics is not None else Semantics.from_env()).generator_rng == "numpy":
+            raise NotImplementedError("auto_reset='regenerate' draws from the build's generator; generator_rng='numpy' "
+                                      "re-creates the seed's instance at every reset, as upstream does")
         self.auto_reset = bool(auto_reset)
         # True: two alternating output sets; "single": ONE set, overwritten by every step (for callers that consume the
         # observation before the next step: a tensor of <= ~200 MB rewritten in place stays largely inside the 256 MiB
@@ -152,6 +155,11 @@ class VecPogema:
         gc = self.grid_config
         B, H, Wd, A = self.batch, self.height, self.width, self.num_agents
         seed0 = self._resolve_seed(seed)
+        if self._numpy_generator():
+            from .nprng import np_generate_host
+            obstacles, agents, targets, status = np_generate_host(self._numpy_seeds(seed0), H, Wd, A, gc.density, gc.map)
+            self._raise_unplaceable(status)
+            return obstacles, agents, targets
         agents = np.empty((B, A, 2), dtype=np.int32)
         targets = np.empty((B, A, 2), dtype=np.int32)
         if gc.map is not None:
@@ -231,6 +239,10 @@ class VecPogema:
         d_obst = torch.from_numpy(obstacles).to(self.device)
         d_agents = torch.from_numpy(agents_xy).to(self.device)
         d_targets = torch.from_numpy(targets_xy).to(self.device)
+        return self._install_device_state(d_obst, d_agents, d_targets)
+
+    def _install_device_state(self, d_obst, d_agents, d_targets):
+        """pgx_reset_from_state on device tensors already in the ABI's shapes and dtypes."""
         _lib.check(self._lib.pgx_reset_from_state(self._handle, d_obst.data_ptr(), d_agents.data_ptr(),
                                                   d_targets.data_ptr(), self._stream()))
         self._initial = (d_obst, d_agents, d_targets)  # initial state; xy of POMAPF/MAPF views is relative to it
@@ -242,6 +254,21 @@ class VecPogema:
         if seed is None:
             seed = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0] >> 1)
         return int(seed) & 0xFFFFFFFFFFFFFFFF
+
+    def _numpy_generator(self) -> bool:
+        """Semantics.generator_rng == 'numpy' applies wherever the positions are random (no agents_xy, no possible_*)."""
+        gc = self.grid_config
+        return self.semantics.generator_rng == "numpy" and gc.agents_xy is None and not self._possible
+
+    def _numpy_seeds(self, seed0: int):
+        """Env i is upstream's environment with GridConfig.seed = seed + env_index_base + i."""
+        return (np.uint64(seed0) + np.uint64(self.env_index_base) + np.arange(self.batch, dtype=np.uint64))
+
+    def _raise_unplaceable(self, status):
+        bad = np.flatnonzero(np.asarray(status))
+        if bad.size:
+            raise OverflowError(f"cannot place {self.num_agents} start/target pairs in {bad.size} of {self.batch} envs "
+                                f"(first: env {int(bad[0])}); lower num_agents or density")
 
     def _shared_map_tensor(self):
         gc = self.grid_config
@@ -262,7 +289,17 @@ class VecPogema:
         seed + env_index_base + i; `generate()` yields the same instances on the host) and returns (obs, infos).
         With an explicit `map` AND `agents_xy`/`targets_xy` in the GridConfig nothing is random: that state is installed."""
         gc = self.grid_config
-        if gc.map is not None and (gc.agents_xy is not None or self._possible):
+        if self._numpy_generator():
+            from .nprng import np_generate
+            resolved = self._resolve_seed(seed)
+            with np.errstate(over="ignore"):
+                seeds = self._numpy_seeds(resolved)
+            obstacles, agents, targets, status = np_generate(seeds, self.height, self.width, self.num_agents, gc.density,
+                                                             self.device, gc.map)
+            self._raise_unplaceable(status.cpu().numpy())  # reset is not the hot path: one sync
+            self._reset_seed = resolved
+            obs = self._install_device_state(obstacles, agents, targets)
+        elif gc.map is not None and (gc.agents_xy is not None or self._possible):
             obstacles, agents, targets = self.generate(seed)
             # user-supplied cells: always validated; an obstacle under a start/target is freed with a warning
             obs = self.reset_from_state(obstacles, agents, targets, validate=True, on_obstacle="free")
@@ -294,6 +331,9 @@ class VecPogema:
         if gc.map is not None and (gc.agents_xy is not None or self._possible):
             raise NotImplementedError("reset_where draws random instances on the device; this GridConfig fixes the "
                                       "agents or restricts them to possible_*_xy (host path)")
+        if self._numpy_generator():
+            raise NotImplementedError("reset_where draws from the build's generator; with generator_rng='numpy' call "
+                                      "reset(seed=...) (upstream re-creates the same instance for a fixed seed)")
         if seed is None:
             seed = self._reset_seed
         shared = self._shared_map_tensor()

@@ -58,8 +58,9 @@ class _Env:
         if gc.map is not None and gc.agents_xy is not None:
             obstacles, agents, targets = np.array(gc.map, np.uint8), gc.agents_xy, gc.targets_xy
         else:
-            obstacles, agents, targets = _G.generate_instance(seed or 0, 0, h, w, gc.num_agents, gc.density,
-                                                              given_map=gc.map)
+            # upstream's generator as recalled, written with numpy itself (the checker of pgx_np_generate)
+            obstacles, agents, targets = _G.generate_instance_numpy(seed or 0, h, w, gc.num_agents, gc.density,
+                                                                    given_map=gc.map)
         self._oracle = _Oracle(obstacles, agents, targets, obs_radius=gc.obs_radius, collision_system=gc.collision_system,
                                on_target=gc.on_target, max_episode_steps=gc.max_episode_steps, seed=gc.seed or 0)
         return self._oracle._obs(), [{"is_active": True} for _ in range(gc.num_agents)]

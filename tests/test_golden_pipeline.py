@@ -87,6 +87,28 @@ def test_comparison_detects_a_wrong_fixture(fixtures, tmp_path):
         tgr.compare_with_fixture(oracle_rollout, str(bad))
 
 
+def test_generator_pin_on_the_loaded_fixtures(fixtures, tmp_path):
+    """The instance-generator pin: host build of the generator kernel == the recorded initial state for every fixture,
+    and it has teeth (a fixture from another seed fails)."""
+    from pogema_amd.nprng import np_generate_host
+    for path in fixtures:
+        assert tgr.compare_generator_with_fixture(np_generate_host, path)
+    z = dict(np.load(fixtures[0], allow_pickle=False))
+    z["grid_seed"] = np.asarray(int(z["grid_seed"]) + 1)
+    bad = tmp_path / "reference_bad_seed.npz"
+    np.savez_compressed(bad, **z)
+    with pytest.raises(AssertionError):
+        tgr.compare_generator_with_fixture(np_generate_host, str(bad))
+
+
+@pytest.mark.gpu
+def test_device_generator_pin_on_the_loaded_fixtures(fixtures):
+    from pogema_amd.nprng import np_generate
+    for path in fixtures:
+        assert tgr.compare_generator_with_fixture(
+            lambda *a: tuple(v.cpu().numpy() for v in np_generate(*a)), path)
+
+
 @pytest.mark.gpu
 def test_engine_passes_the_loaded_fixtures(fixtures):
     for path in fixtures:

@@ -8,7 +8,12 @@ stream the implementations do not reproduce (docs/SPEC.md S5).  The recorded tar
 after every step the implementation's targets are overwritten with the fixture's (`pgx_set_targets`), so positions,
 rewards, flags and observations stay comparable for the whole episode.  Only the draw itself is excluded: for a
 (step, agent) that reached its goal in that step the new target and the target plane of that step's observation are
-taken from the fixture."""
+taken from the fixture.
+
+Instance generator: a fixture that records `grid_seed` and `density` also pins the numpy-stream generator
+(pgx_np_generate / Semantics.generator_rng='numpy'): the instance it draws for that seed must be the fixture's initial
+state.  A failure of THAT test alone means the recalled `placing` rule or call order differs from the real package --
+the step semantics are unaffected (every other test starts from the recorded initial state)."""
 import glob
 import os
 
@@ -46,6 +51,30 @@ def compare_with_fixture(run, path):
         got["obs"] = got["obs"].copy()
         got["obs"][:, :, :, 2] = np.where(drew[..., None, None], ref["obs"][:, :, :, 2], got["obs"][:, :, :, 2])
     assert_rollouts_equal(ref, got, os.path.basename(path))
+
+
+def compare_generator_with_fixture(generate, path):
+    """`generate(seeds, H, W, A, density)` -> (obstacles, agents, targets, status) as numpy; False when the fixture
+    does not record where its instance came from."""
+    z = np.load(path, allow_pickle=False)
+    if "grid_seed" not in z.files:
+        return False
+    H, W = z["obstacles"].shape
+    o, a, t, st = (np.asarray(v) for v in generate([int(z["grid_seed"])], H, W, z["agents_xy0"].shape[0], float(z["density"])))
+    what = os.path.basename(path)
+    assert st[0] == 0, f"{what}: generator could not place the agents"
+    np.testing.assert_array_equal(o[0], z["obstacles"], err_msg=f"{what}: obstacles")
+    np.testing.assert_array_equal(a[0], z["agents_xy0"], err_msg=f"{what}: starts")
+    np.testing.assert_array_equal(t[0], z["targets_xy0"], err_msg=f"{what}: targets")
+    return True
+
+
+@pytest.mark.skipif(not FIXTURES, reason="no reference fixtures: the reference is not available in this container")
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p) for p in FIXTURES])
+def test_numpy_generator_matches_reference_fixture(path):
+    from pogema_amd.nprng import np_generate_host
+    if not compare_generator_with_fixture(np_generate_host, path):
+        pytest.skip("fixture predates grid_seed/density")
 
 
 @pytest.mark.skipif(not FIXTURES, reason="no reference fixtures: the reference is not available in this container")

@@ -18,7 +18,9 @@ outputs) are committed.
 
 What is recorded per case: the initial state actually used by the reference (obstacles, agents_xy,
 targets_xy read back from its Grid, unpadded), the action stream, and per step agents_xy, targets_xy,
-is_active, rewards, terminated, truncated and the full float32 observations.
+is_active, rewards, terminated, truncated and the full float32 observations; plus the GridConfig numbers the random
+instance came from (grid_seed, density), which pin the numpy-stream instance generator (pgx_np_generate,
+Semantics.generator_rng='numpy') against the reference's.
 """
 import argparse
 import itertools
@@ -116,7 +118,7 @@ def main():
         name = f"reference_{g['size']}x{g['num_agents']}_{cs}_{ot}_s{seed}.npz"
         np.savez_compressed(os.path.join(out_dir, name), obstacles=obstacles, agents_xy0=agents0, targets_xy0=targets0,
                             actions=actions, obs_radius=r, collision_system=cs, on_target=ot,
-                            max_episode_steps=gc.max_episode_steps,
+                            max_episode_steps=gc.max_episode_steps, grid_seed=seed, density=gc.density,
                             **{k: np.asarray(v) for k, v in rec.items()})
         n += 1
     print(f"wrote {n} fixtures to {out_dir}")

@@ -233,6 +233,100 @@ class EngineStep:
                     f"into the slowest buffer: {pl['buffer_gbs']:.0f} GB/s)")
         return f"{self.nbuf} output buffer(s) as torch's allocator returned them (no zone placement)"
 
+    def box_store_stream_gbs(self):
+        """What a bare store stream sustains on THIS box where the buffers lie (the zone walk's probe: 2 x 384 MiB,
+        8192 chunks, as placed) -- boxes of the pool differ by 25 % here, the kernel cannot beat it.  None without a walk."""
+        pl = getattr(self.env, "placement", None) or {}
+        us = pl.get("final_us") or 0.0
+        return (2 * (384 << 20) / (us * 1e-6) / 1e9) if us > 0 else None
+
+    def close(self):
+        self.env.close()
+
+
+class PipelinedStep:
+    """Secondary figure: the same batch as TWO engines on two HIP streams, stepped alternately and never joined
+    (pogema_amd.PipelinedVecPogema -- double-buffered sampling).  One `step` here = one step of BOTH halves."""
+
+    def __init__(self, args, rank, device, batch, env_base, size, agents, r, parts=2):
+        import torch
+        from pogema_amd import GridConfig, PipelinedVecPogema
+        self.torch = torch
+        gc = GridConfig(size=size, density=args.density, num_agents=agents, obs_radius=r, seed=0,
+                        collision_system=args.collision, on_target=args.on_target,
+                        max_episode_steps=args.max_episode_steps)
+        self.env = PipelinedVecPogema(gc, batch=batch, device=device, parts=parts, env_index_base=env_base, auto_reset=True,
+                                      reuse_buffers=True,
+                                      obs_dtype=torch.float32 if args.obs_dtype == "float32" else torch.uint8)
+        self.env.reset(seed=0)
+        tdt = {"int8": torch.int8, "int32": torch.int32, "int64": torch.int64}[args.action_dtype]
+        gen = torch.Generator(device=device)
+        gen.manual_seed(1 + rank)
+        self.pool = [[torch.randint(0, 5, (batch // parts, agents), generator=gen, device=device).to(tdt) for _ in range(parts)]
+                     for _ in range(16)]
+        self.env.synchronize()
+        torch.cuda.synchronize(device)
+        self.i = 0
+
+    def run(self, steps):
+        for _ in range(steps):
+            self.env.step(self.pool[self.i % len(self.pool)])
+            self.i += 1
+
+    def measure(self, steps, windows=3):
+        torch = self.torch
+        self.run(max(8, steps // 10))
+        out = []
+        for _ in range(windows):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            self.run(steps)
+            torch.cuda.synchronize()
+            out.append((time.perf_counter() - t0) / steps * 1e3)
+        return statistics.median(out)
+
+    def close(self):
+        self.env.close()
+
+
+class RolloutStep:
+    """Secondary figure: K steps per launch (pgx_rollout), observation ring of two zone-spread slots -- the step
+    kernel's work with the launch boundaries between steps removed."""
+
+    def __init__(self, args, rank, device, batch, env_base, size, agents, r, k=64):
+        import torch
+        from pogema_amd import GridConfig, VecPogema
+        self.torch, self.k = torch, k
+        gc = GridConfig(size=size, density=args.density, num_agents=agents, obs_radius=r, seed=0,
+                        collision_system=args.collision, on_target=args.on_target,
+                        max_episode_steps=args.max_episode_steps)
+        self.env = VecPogema(gc, batch=batch, device=device, env_index_base=env_base, auto_reset=True,
+                             obs_dtype=torch.float32 if args.obs_dtype == "float32" else torch.uint8)
+        self.env.reset(seed=0)
+        tdt = {"int8": torch.int8, "int32": torch.int32, "int64": torch.int64}[args.action_dtype]
+        gen = torch.Generator(device=device)
+        gen.manual_seed(1 + rank)
+        self.actions = torch.randint(0, 5, (k, batch, agents), generator=gen, device=device).to(tdt)
+        # ring of at least 1 GiB (and at least two slots): a smaller one would sit partly in the 256 MiB Infinity Cache
+        obs_bytes = batch * agents * 3 * (2 * r + 1) ** 2 * (4 if args.obs_dtype == "float32" else 1)
+        self.slots = min(k, max(2, -(-(1 << 30) // obs_bytes)))
+
+    def measure(self, steps, windows=3):
+        torch = self.torch
+        launches = max(1, steps // self.k)
+        self.env.rollout(self.actions, obs_slots=self.slots)
+        out = []
+        for _ in range(windows):
+            torch.cuda.synchronize()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            for _ in range(launches):
+                self.env.rollout(self.actions, obs_slots=self.slots)
+            ev1.record()
+            torch.cuda.synchronize()
+            out.append(ev0.elapsed_time(ev1) / (launches * self.k))
+        return statistics.median(out)
+
     def close(self):
         self.env.close()
 
@@ -284,6 +378,8 @@ def main(argv=None):
     ap.add_argument("--no-default-placement", action="store_true",
                     help="skip the extra window that times the unprobed (default allocator) buffers")
     ap.add_argument("--no-obs", action="store_true", help="diagnostic: skip the observation write")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary figures (two pipelined engines; K-step rollout launches)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)  # tests only, see StubStep
     args = ap.parse_args(argv)
@@ -394,6 +490,24 @@ def main(argv=None):
         del plain
         torch.cuda.empty_cache()
 
+    # secondary figures, never `value`: the same work without the launch boundary in the way
+    extras = {}
+    if (not args.stub and not args.no_extras and world == 1 and args.graph <= 0 and args.auto_reset == "restore"
+            and not args.no_obs and args.buffers == 2):
+        n = min(args.steps, 1000)
+        if batch % 2 == 0:
+            ps = PipelinedStep(args, rank, device, batch, env_base, size, agents, r)
+            extras["pipelined"] = {"engines": 2, "ms_per_step": ps.measure(n)}
+            ps.close()
+            del ps
+            torch.cuda.empty_cache()
+        rs = RolloutStep(args, rank, device, batch, env_base, size, agents, r)
+        extras["rollout"] = {"steps_per_launch": rs.k, "obs_slots": rs.slots, "ms_per_step": rs.measure(n),
+                             "placement_spread": bool((rs.env.placement or {}).get("spread", False))}
+        rs.close()
+        del rs
+        torch.cuda.empty_cache()
+
     if rank == 0:
         n_agent_steps = total_envs * agents * args.steps
         value = n_agent_steps / elapsed
@@ -434,8 +548,25 @@ def main(argv=None):
                          "kernel": "pgx::step_kernel", "kernel_ms": kernel_ms, "kernel_ms_per_rank": per_rank_kernel,
                          "kernel_ms_windows": kernel,
                          "default_placement_kernel_ms": default_ms,
+                         "box_store_stream_gbs": None if args.stub else step.box_store_stream_gbs(),
                          "algorithmic_bytes_per_agent_step": bpas, "algorithmic_bytes_per_launch": alg_bytes},
         }
+        if "pipelined" in extras:
+            e = extras["pipelined"]
+            e.update(value=batch * agents / (e["ms_per_step"] * 1e-3), unit="agent-steps/s",
+                     frac=alg_bytes / (e["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     what="the same batch as two engines on two HIP streams, stepped alternately and never joined "
+                          "(PipelinedVecPogema, double-buffered sampling): one half's launch boundary lies under the other "
+                          "half's observation stream; wall clock over both halves")
+        if "rollout" in extras:
+            e = extras["rollout"]
+            e.update(value=batch * agents / (e["ms_per_step"] * 1e-3), unit="agent-steps/s",
+                     frac=alg_bytes / (e["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     what="pgx_rollout: 64 steps per launch with the actions given up front, observations into a ring of "
+                          "obs_slots tensors (>= 1 GiB in total); bit-identical with 64 pgx_step calls; HIP events around the "
+                          "launches")
+        if extras:
+            line["secondary"] = extras
         if world == 1 and not args.no_cpu_baseline and not args.stub:
             line["cpu_baseline"] = cpu_baseline(size, agents, r, args.collision, args.density, args.max_episode_steps,
                                                 args.cpu_seconds)

@@ -192,6 +192,38 @@ int pgx_get_map(pgx_env* env, uint8_t* obstacles, void* stream);
 int pgx_step(pgx_env* env, const void* actions, int action_dtype, void* obs, float* rewards,
              uint8_t* terminated, uint8_t* truncated, uint8_t* is_active, void* stream);
 
+/* K steps in ONE launch: the same as `steps` consecutive pgx_step calls with actions[t] -- bit for bit, state and outputs
+ * -- for callers that have the actions up front (executing MAPF plans, scripted or random policies, replaying recorded
+ * episodes): upstream, the `for t in range(K): env.step(actions[t])` loop around `Pogema.step`.  Every workgroup takes its
+ * own environments through all K steps, so there is no launch boundary between steps and one wave's collision resolve
+ * runs under the other waves' observation streams.  All pointers are device pointers.
+ *   actions       [steps, batch, agents] of action_dtype
+ *   obs           [obs_slots, batch, agents, 3, 2r+1, 2r+1] f32 (u8 with PGX_OBS_U8) or NULL; step t writes slot
+ *                 t % obs_slots: obs_slots = steps keeps the whole trajectory, 1 only the last observation.
+ *                 obs_slot_stride: bytes from one slot to the next; 0 = dense.  (pgx_buffers_stride() for a ring made
+ *                 of zone-spread buffers.)
+ *   rewards       [steps, batch, agents] f32
+ *   terminated, truncated   [steps, batch, agents] u8
+ *   is_active     [steps, batch, agents] u8 or NULL
+ *   episode_done  [steps, batch] u8 or NULL          1 where the env's episode finished in that step
+ *   metrics       [steps, batch, 6] f32 or NULL      written only where episode_done is 1 (as pgx_set_metrics_buffers)
+ * The buffers of pgx_set_metrics_buffers are not touched.  auto_reset works as in pgx_step; pgx_regenerate has no
+ * place inside the launch (PGX_E_INVALID is never returned for it: the caller simply does not call it). */
+typedef struct pgx_rollout_io {
+    const void* actions;
+    void* obs;
+    float* rewards;
+    uint8_t* terminated;
+    uint8_t* truncated;
+    uint8_t* is_active;
+    uint8_t* episode_done;
+    float* metrics;
+    int32_t action_dtype;
+    int32_t obs_slots;
+    int64_t obs_slot_stride;
+} pgx_rollout_io;
+int pgx_rollout(pgx_env* env, int32_t steps, const pgx_rollout_io* io, void* stream);
+
 /* Overwrites the current targets of the agents flagged in `agent_mask` (device u8 [batch, agents]; NULL = all agents).
  *   target_xy  device i32 [batch, agents, 2]  unpadded (row, col); must be free cells inside the map (not checked)
  * `PogemaLifeLong` draws new targets from per-agent numpy generators (upstream pogema/envs.py `_generate_new_target`,
@@ -259,6 +291,8 @@ typedef struct pgx_buffers_info {
 } pgx_buffers_info;
 int pgx_buffers_create(int device, size_t bytes, int count, double max_spacer_gib, pgx_buffers** out);
 void* pgx_buffers_ptr(pgx_buffers* pool, int index); /* device pointer of buffer `index`, NULL if out of range */
+int64_t pgx_buffers_stride(pgx_buffers* pool);       /* all buffers lie in ONE virtual range: ptr(i) = ptr(0) + i * stride,
+                                                        stride = bytes rounded up to 2 MiB (pgx_rollout_io.obs_slot_stride) */
 int pgx_buffers_get_info(pgx_buffers* pool, pgx_buffers_info* info);
 int pgx_buffers_destroy(pgx_buffers* pool);          /* synchronises the device, then unmaps and frees        */
 

@@ -7,7 +7,7 @@ __version__ = "0.1.0"
 
 from .semantics import Semantics
 
-__all__ = ["GridConfig", "Semantics", "VecPogema", "Pogema", "pogema_v0", "Easy8x8", "Normal8x8", "Hard8x8", "Easy16x16",
+__all__ = ["GridConfig", "Semantics", "VecPogema", "PipelinedVecPogema", "Pogema", "pogema_v0", "Easy8x8", "Normal8x8", "Hard8x8", "Easy16x16",
            "Hard16x16", "Easy32x32", "Hard32x32", "Easy64x64", "Hard64x64"]
 
 
@@ -16,6 +16,9 @@ def __getattr__(name):
     if name == "VecPogema":
         from .vec_env import VecPogema
         return VecPogema
+    if name == "PipelinedVecPogema":
+        from .pipeline import PipelinedVecPogema
+        return PipelinedVecPogema
     if name in ("Pogema", "pogema_v0", "PogemaParallel"):
         from . import envs
         return getattr(envs, name)

@@ -51,7 +51,7 @@ EXPORTED_SYMBOLS = (
     "pgx_reset_from_state", "pgx_reset_random", "pgx_regenerate", "pgx_regenerate_failures", "pgx_get_map", "pgx_step", "pgx_observe", "pgx_set_metrics_buffers", "pgx_get_state", "pgx_generate", "pgx_place_agents",
     "pgx_snapshot_bytes", "pgx_save_snapshot", "pgx_load_snapshot", "pgx_time_observe", "pgx_bad_action_count",
     "pgx_buffers_create", "pgx_buffers_ptr", "pgx_buffers_get_info", "pgx_buffers_destroy", "pgx_set_targets",
-    "pgx_np_streams", "pgx_np_streams_host", "pgx_np_generate", "pgx_np_generate_host",
+    "pgx_np_streams", "pgx_np_streams_host", "pgx_np_generate", "pgx_np_generate_host", "pgx_rollout", "pgx_buffers_stride",
 )
 
 
@@ -65,6 +65,12 @@ class PgxBuffersInfo(C.Structure):
     _fields_ = [("bytes", C.c_int64), ("count", C.c_int32), ("spread", C.c_int32), ("candidates", C.c_int32),
                 ("reserved0", C.c_int32), ("same_zone_us", C.c_float), ("final_us", C.c_float), ("spacer_gib", C.c_double),
                 ("buffer_gbs", C.c_float), ("reserved1", C.c_float)]
+
+
+class PgxRolloutIO(C.Structure):
+    _fields_ = [("actions", C.c_void_p), ("obs", C.c_void_p), ("rewards", C.c_void_p), ("terminated", C.c_void_p),
+                ("truncated", C.c_void_p), ("is_active", C.c_void_p), ("episode_done", C.c_void_p), ("metrics", C.c_void_p),
+                ("action_dtype", C.c_int32), ("obs_slots", C.c_int32), ("obs_slot_stride", C.c_int64)]
 
 
 class PgxConfig(C.Structure):
@@ -129,6 +135,10 @@ def load() -> C.CDLL:
     lib.pgx_np_generate.restype = C.c_int
     lib.pgx_np_generate_host.argtypes = [vp, i32, i32, i32, i32, C.c_double, vp, vp, vp, vp, vp, vp]
     lib.pgx_np_generate_host.restype = C.c_int
+    lib.pgx_buffers_stride.argtypes = [vp]
+    lib.pgx_buffers_stride.restype = C.c_int64
+    lib.pgx_rollout.argtypes = [vp, i32, C.POINTER(PgxRolloutIO), vp]
+    lib.pgx_rollout.restype = C.c_int
     lib.pgx_set_targets.argtypes = [vp, vp, vp, vp]
     lib.pgx_set_targets.restype = C.c_int
     lib.pgx_bad_action_count.argtypes = [vp, vp]

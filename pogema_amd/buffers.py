@@ -35,9 +35,9 @@ class _Owner:
 
 
 class _Cai:
-    def __init__(self, ptr, shape, typestr, owner):
+    def __init__(self, ptr, shape, typestr, owner, strides=None):
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
-                                         "version": 2, "strides": None}
+                                         "version": 2, "strides": strides}
         self._owner = owner  # the tensor references this object, this object references the pool
 
 
@@ -77,3 +77,14 @@ class ZoneBuffers:
             if t.data_ptr() != ptr:
                 raise RuntimeError("torch copied the zone buffer instead of wrapping it")
             self.tensors.append(t)
+        # all buffers lie in one virtual range at a constant stride: the pool as ONE [count, *shape] tensor whose first
+        # axis steps by that stride (the observation ring of VecPogema.rollout)
+        self.stride_bytes = int(lib.pgx_buffers_stride(handle))
+        item = 4 if dtype == torch.float32 else 1
+        dense = [item]
+        for n in reversed(tuple(shape)[1:]):
+            dense.insert(0, dense[0] * n)
+        self.ring = torch.as_tensor(_Cai(lib.pgx_buffers_ptr(handle, 0), (count,) + tuple(shape), _TYPESTR[dtype], self._owner,
+                                         strides=(self.stride_bytes,) + tuple(dense)), device=torch.device("cuda", index))
+        if self.ring.data_ptr() != self.tensors[0].data_ptr() or self.ring.stride(0) * item != self.stride_bytes:
+            raise RuntimeError("torch copied the zone buffers instead of wrapping them")

@@ -621,6 +621,47 @@ int pgx_step(pgx_env* e, const void* actions, int action_dtype, void* obs, float
     return PGX_OK;
 }
 
+int pgx_rollout(pgx_env* e, int32_t steps, const pgx_rollout_io* io, void* stream) {
+    if (!e || !io || !io->actions || !io->rewards || !io->terminated || !io->truncated)
+        return fail(PGX_E_INVALID, "pgx_rollout: null argument");
+    if (steps < 1) return fail(PGX_E_INVALID, "pgx_rollout: steps must be >= 1, got %d", steps);
+    if (io->action_dtype < 0 || io->action_dtype > 2) return fail(PGX_E_INVALID, "pgx_rollout: bad action_dtype %d", io->action_dtype);
+    if (io->obs && io->obs_slots < 1) return fail(PGX_E_INVALID, "pgx_rollout: obs given but obs_slots = %d", io->obs_slots);
+    if (!e->has_state) return fail(PGX_E_STATE, "pgx_rollout called before a reset");
+    DeviceGuard guard(e->device);
+    if (guard.err != hipSuccess) return fail(PGX_E_HIP, "cannot select device: %s", hipGetErrorString(guard.err));
+    pgx::StepParams p;
+    fill_params(e, p);
+    p.mode = pgx::MODE_STEP;
+    p.action_dtype = io->action_dtype;
+    p.actions = io->actions;
+    p.obs = static_cast<float*>(io->obs);
+    p.rewards = io->rewards;
+    p.terminated = io->terminated;
+    p.truncated = io->truncated;
+    p.act_out = io->is_active;
+    p.metrics_out = io->metrics;
+    p.episode_done = io->episode_done;
+    const int64_t agents = (int64_t)e->cfg.batch * e->cfg.num_agents;
+    const int64_t W = 2 * e->cfg.obs_radius + 1;
+    static const int64_t action_bytes[3] = {1, 4, 8};
+    pgx::RolloutParams rp;
+    rp.steps = steps;
+    rp.obs_slots = io->obs ? io->obs_slots : 1;
+    rp.actions_stride = agents * action_bytes[io->action_dtype];
+    rp.agents_stride = agents;
+    rp.envs_stride = e->cfg.batch;
+    rp.obs_stride = agents * 3 * W * W * (p.obs_u8 ? 1 : 4);
+    if (io->obs && io->obs_slot_stride != 0) {
+        if (io->obs_slot_stride < rp.obs_stride || (io->obs_slot_stride & 15) != 0)
+            return fail(PGX_E_INVALID, "pgx_rollout: obs_slot_stride %lld is smaller than one observation tensor (%lld bytes) or not a multiple of 16",
+                        (long long)io->obs_slot_stride, (long long)rp.obs_stride);
+        rp.obs_stride = io->obs_slot_stride;
+    }
+    PGX_HIP(pgx::launch_rollout(p, rp, e->geo, (hipStream_t)stream));
+    return PGX_OK;
+}
+
 int pgx_set_targets(pgx_env* e, const int32_t* target_xy, const uint8_t* agent_mask, void* stream) {
     if (!e || !target_xy) return fail(PGX_E_INVALID, "pgx_set_targets: null argument");
     if (!e->has_state) return fail(PGX_E_STATE, "pgx_set_targets called before a reset");

@@ -128,7 +128,9 @@ struct pgx_buffers {
     int device = 0;
     size_t bytes = 0, first = 0, second = 0;  // requested bytes; sizes of the two physical halves
     int count = 0;
-    std::vector<Range> buf;
+    size_t stride = 0;   // bytes between consecutive buffers: round_up(bytes, 2 MiB)
+    Range all;           // ONE virtual range: buffer i at all.va + i * stride, parts 2i (first half) and 2i + 1
+    void* va_of(int i) const { return (char*)all.va + (size_t)i * stride; }
     pgx_buffers_info info{};
 };
 
@@ -165,7 +167,7 @@ hipError_t probe_us(void* lo, void* hi, size_t half_bytes, float* us) {
 }
 
 void destroy(pgx_buffers* p) {
-    for (Range& r : p->buf) r.release();
+    p->all.release();
     delete p;
 }
 
@@ -216,13 +218,16 @@ void find_other_zone(int device, size_t budget, std::vector<Range>& held, pgx_bu
         info.candidates += 1;
         if (getenv("PGX_DEBUG")) fprintf(stderr, "[pgx_buffers] %4.0f GiB of spacers: candidate %.1f us (same-zone pair %.1f us)\n", (double)spacer_bytes / (double)GiB, t, t_same);
         // Two kinds of other zone were seen (profiles/r2/placement_walk_scan.txt): one pairs with the reference at
-        // ~6.75 TB/s, one at ~6.3-6.4 TB/s.  The first kind is taken at once; the second only after ten more spacers
-        // have failed to reach the first (or when the budget ends while still in it).
-        const bool strong = t <= t_spread_abs, weak = t < 0.9f * t_same;
+        // ~6.75 TB/s, one at ~6.3-6.4 TB/s (~90 GiB wide, its candidates scatter around 0.88-0.92 of the same-zone time).
+        // The first kind is taken at once; the second only after 14 more spacers (112 GiB) have failed to reach the
+        // first, when the walk has clearly left it again (a candidate back at the same-zone time), or when the budget
+        // ends while still in it.
+        constexpr int WEAK_LIMIT = 14;
+        const bool strong = t <= t_spread_abs, weak = t < 0.94f * t_same;
         if (weak && !strong) weak_run += 1;
-        else if (!weak) weak_run = weak_run > 0 ? 10 : 0;  // left a weak zone without finding better: take the next one
+        else if (t >= 0.97f * t_same && weak_run > 0) weak_run = WEAK_LIMIT;  // left it without finding better: take the next one
         const bool last = spacer_bytes + 2 * SPACER > budget;
-        if (!getenv("PGX_ZONE_SCAN") && (strong || (weak && (weak_run > 10 || last)))) {
+        if (!getenv("PGX_ZONE_SCAN") && (strong || (weak && (weak_run > WEAK_LIMIT || last)))) {
             info.final_us = t;
             *found = true;
             // the first faster candidate may itself straddle the boundary: one more spacer puts what is allocated
@@ -263,7 +268,7 @@ int pgx_buffers_create(int device, size_t bytes, int count, double max_spacer_gi
     const size_t total = round_up(bytes, GRANULE);
     p->first = total >= 2 * GRANULE ? round_up(total / 2, GRANULE) : total;
     p->second = total - p->first;
-    p->buf.resize(count);
+    p->stride = total;
     p->info.bytes = (int64_t)bytes;
     p->info.count = count;
     std::vector<Range> held;  // spacers, reference and candidate chunks of the zone walk
@@ -276,12 +281,15 @@ int pgx_buffers_create(int device, size_t bytes, int count, double max_spacer_gi
         return pgx::fail_msg(code, "%s", msg.c_str());
     };
     auto code_of = [](hipError_t e) { return e == hipErrorOutOfMemory ? PGX_E_NOMEM : PGX_E_HIP; };
-    // 1. virtual ranges + first halves (the zone the allocator is in right now)
-    for (int i = 0; i < count; ++i) {
-        hipError_t e = p->buf[i].reserve(total);
+    // 1. one virtual range for all buffers (a rollout's observation ring needs a constant stride) + first halves (the
+    //    zone the allocator is in right now)
+    {
+        const hipError_t e = p->all.reserve((size_t)count * total);
         if (e != hipSuccess) return bail(PGX_E_NOMEM, "hipMemAddressReserve", e);
-        p->buf[i].parts.resize(p->second ? 2 : 1);
-        e = map_part(device, p->buf[i].va, p->first, p->buf[i].parts[0]);
+        p->all.parts.resize((size_t)2 * count);
+    }
+    for (int i = 0; i < count; ++i) {
+        const hipError_t e = map_part(device, p->va_of(i), p->first, p->all.parts[2 * i]);
         if (e != hipSuccess) return bail(code_of(e), "hipMemCreate/hipMemMap (first half)", e);
     }
     // 2. walk the allocator into another zone.  Buffers below 256 MiB are left alone: a repeated stream of that size is
@@ -298,11 +306,11 @@ int pgx_buffers_create(int device, size_t bytes, int count, double max_spacer_gi
     }
     // 3. second halves, right behind the last candidate of the walk (everything the walk allocated is still held)
     for (int i = 0; i < count && p->second; ++i) {
-        const hipError_t e = map_part(device, (char*)p->buf[i].va + p->first, p->second, p->buf[i].parts[1]);
+        const hipError_t e = map_part(device, (char*)p->va_of(i) + p->first, p->second, p->all.parts[2 * i + 1]);
         if (e != hipSuccess) return bail(code_of(e), "hipMemCreate/hipMemMap (second half)", e);
     }
-    for (int i = 0; i < count; ++i) {
-        const hipError_t e = grant_access(device, p->buf[i].va, total);
+    {
+        const hipError_t e = grant_access(device, p->all.va, (size_t)count * total);
         if (e != hipSuccess) return bail(PGX_E_HIP, "hipMemSetAccess", e);
     }
     for (Range& s : held) s.release();
@@ -314,7 +322,7 @@ int pgx_buffers_create(int device, size_t bytes, int count, double max_spacer_gi
         double worst = 0.0;
         for (int i = 0; i < count; ++i) {
             float t = 0.f;
-            if (probe_us(p->buf[i].va, (char*)p->buf[i].va + p->first, p->second, &t) != hipSuccess || t <= 0.f) continue;
+            if (probe_us(p->va_of(i), (char*)p->va_of(i) + p->first, p->second, &t) != hipSuccess || t <= 0.f) continue;
             const double gbs = 2.0 * (double)p->second / ((double)t * 1e-6) / 1e9;
             if (worst == 0.0 || gbs < worst) worst = gbs;
         }
@@ -328,8 +336,10 @@ int pgx_buffers_create(int device, size_t bytes, int count, double max_spacer_gi
 
 void* pgx_buffers_ptr(pgx_buffers* p, int index) {
     if (!p || index < 0 || index >= p->count) return nullptr;
-    return p->buf[index].va;
+    return p->va_of(index);
 }
+
+int64_t pgx_buffers_stride(pgx_buffers* p) { return p ? (int64_t)p->stride : 0; }
 
 int pgx_buffers_get_info(pgx_buffers* p, pgx_buffers_info* info) {
     if (!p || !info) return pgx::fail_msg(PGX_E_INVALID, "pgx_buffers_get_info: null argument");

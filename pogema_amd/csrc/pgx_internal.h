@@ -104,6 +104,16 @@ struct StepParams {
     unsigned long long* dbg;  // diagnostic (PGX_FLAGS bit2): per-workgroup {start, resolve done, first store, end} clocks
 };
 
+// pgx_rollout: what changes from one step of the launch to the next
+struct RolloutParams {
+    int32_t steps;
+    int32_t obs_slots;        // step t writes observation slot t % obs_slots
+    int64_t actions_stride;   // bytes between the action tensors of consecutive steps
+    int64_t agents_stride;    // batch * num_agents: elements between per-agent outputs of consecutive steps
+    int64_t envs_stride;      // batch: elements between per-env outputs of consecutive steps
+    int64_t obs_stride;       // bytes between observation slots
+};
+
 // How one configuration maps onto the step kernel (pgx_kernels.hip: step_geometry()).
 struct StepGeometry {
     int G;            // lanes per environment group (power of two, 64 when multi_wave)
@@ -119,6 +129,7 @@ StepGeometry step_geometry(int batch, int A, int bmw, int W, bool allow_p16, int
                            int waves_override);
 hipError_t prepare_step(const StepGeometry& g);
 hipError_t launch_step(const StepParams& p, const StepGeometry& g, hipStream_t stream);
+hipError_t launch_rollout(const StepParams& p, const RolloutParams& rp, const StepGeometry& g, hipStream_t stream);
 
 // `only` (device u8 [batch], may be null): pack just the flagged environments
 hipError_t launch_pack_obstacles(const uint8_t* obstacles, const uint8_t* only, uint32_t* bm, int batch, int H, int Wd,

@@ -247,8 +247,12 @@ __device__ __forceinline__ void stream_obs_u8(uint8_t* out, size_t base, int n, 
 // ------------------------------------------------------------------------------------------------
 enum { MISC_FLAGS = 0, MISC_ARRIVED = 16, MISC_UNSOLVED = 17, MISC_OFFGOAL = 18, MISC_WORDS = 32 };
 
-template <int G, bool MW, bool P16>
-__global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const StepParams p) {
+// P / R: the argument blocks, either plain (`const StepParams`, one step per launch) or read through a laundered
+// kernarg pointer (rollout_kernel).  ROLL: step `t` of a pgx_rollout launch -- the per-step I/O tensors are slices t of
+// the caller's [K, ...] buffers (observations: ring slot `slot`), addressed where they are used so that nothing but `t`
+// and `slot` lives across the loop.
+template <int G, bool MW, bool P16, bool ROLL, typename P, typename R>
+__device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int slot) {
     static_assert(!MW || G == 64, "multi-wave environments use full waves");
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
 
@@ -313,9 +317,10 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
         tgt = p.tgt[gi];
         active = p.active[gi] != 0;
         if (p.mode == MODE_STEP) {
-            if (p.action_dtype == 0) act = ((const int8_t*)p.actions)[gi];
-            else if (p.action_dtype == 1) act = ((const int32_t*)p.actions)[gi];
-            else act = (int)((const int64_t*)p.actions)[gi];
+            const size_t ai = ROLL ? gi + (size_t)t * (size_t)rp.agents_stride : gi;
+            if (p.action_dtype == 0) act = ((const int8_t*)p.actions)[ai];
+            else if (p.action_dtype == 1) act = ((const int32_t*)p.actions)[ai];
+            else act = (int)((const int64_t*)p.actions)[ai];
         }
     }
     if (env_ok && p.mode == MODE_STEP) elapsed = p.elapsed[env];
@@ -327,7 +332,8 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
     {
         const uint32_t* g = p.obst + (size_t)env0 * bmw;
         const int n = nenv * bmw;
-        if (!MW && p.stagger > 0 && n <= 16 * 64) {
+        const int stagger = (ROLL && t > 0) ? 0 : p.stagger;  // only the first step of a rollout starts in lockstep
+        if (!MW && stagger > 0 && n <= 16 * 64) {
             // Two cohorts.  Every wave issues ALL its loads at t = 0, while the memory system is idle; then the waves in
             // odd hardware slots sleep for `stagger` x 8128 cycles.  The even slots run their state phase with half the
             // SIMD/LDS contention and start streaming early; the odd slots compute under that stream (their loads are
@@ -340,7 +346,7 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
             const uint32_t slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));  // HW_REG_HW_ID.WAVE_ID
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (slot & 1u)
-                for (int k = 0; k < p.stagger; ++k) __builtin_amdgcn_s_sleep(127);
+                for (int k = 0; k < stagger; ++k) __builtin_amdgcn_s_sleep(127);
 #pragma unroll
             for (int k = 0; k < 16; ++k)
                 if (tid + 64 * k < n) {
@@ -518,10 +524,11 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
             const bool trunc = p.max_steps > 0 && elapsed >= p.max_steps;
             const bool do_reset = p.auto_reset && (all_term || trunc);
             if (valid) {
-                p.rewards[gi] = rew;
-                p.terminated[gi] = term;
-                p.truncated[gi] = trunc ? 1 : 0;
-                if (p.act_out) p.act_out[gi] = active ? 1 : 0;
+                const size_t go = ROLL ? gi + (size_t)t * (size_t)rp.agents_stride : gi;
+                p.rewards[go] = rew;
+                p.terminated[go] = term;
+                p.truncated[go] = trunc ? 1 : 0;
+                if (p.act_out) p.act_out[go] = active ? 1 : 0;
                 if (do_reset) {  // auto-reset wrapper: observation comes from the reset state
                     pos = p.pos0[gi];
                     tgt = p.tgt0[gi];
@@ -546,7 +553,7 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
                     macc.w += n_arrived;
                 }
                 if (finished && p.metrics_out) {
-                    float* mo = p.metrics_out + (size_t)env * 6;
+                    float* mo = p.metrics_out + ((size_t)env + (ROLL ? (size_t)t * (size_t)rp.envs_stride : 0)) * 6;
                     const float fA = (float)A;
                     if (fin) {
                         const int unsolved = A - macc.x;
@@ -563,7 +570,7 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
                         mo[5] = (float)macc.w / (float)denom;
                     }
                 }
-                if (p.episode_done) p.episode_done[env] = finished ? 1 : 0;
+                if (p.episode_done) p.episode_done[(size_t)env + (ROLL ? (size_t)t * (size_t)rp.envs_stride : 0)] = finished ? 1 : 0;
                 p.macc[env] = finished ? make_int4(0, 0, 0, 0) : macc;
             }
         }
@@ -582,6 +589,7 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
     if (dbg && tid == 0) p.dbg[(size_t)blk * 4 + (dbg2 ? 3 : 1)] = wall_clock64();
     if (!p.obs) return;
     lds_sync<MW>();
+    float* const obs_out = ROLL ? reinterpret_cast<float*>(reinterpret_cast<char*>(p.obs) + (size_t)slot * (size_t)rp.obs_stride) : p.obs;
 
     if constexpr (P16) {
         // ---- phase 3 (P16): row masks -> registers -> (sync) -> packed u16 rows over the dead state -------
@@ -646,7 +654,7 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
         if (p.obs_u8) {
             if (dbg && !dbg2 && tid == 0) p.dbg[(size_t)blk * 4 + 2] = wall_clock64();
             const int nrows = nag * 3 * W;
-            stream_obs_u8(reinterpret_cast<uint8_t*>(p.obs), base, n, W, p.w_magic, tid, NT, p.store_policy == 1,
+            stream_obs_u8(reinterpret_cast<uint8_t*>(obs_out), base, n, W, p.w_magic, tid, NT, p.store_policy == 1,
                           [&](int row) -> uint32_t { return row < nrows ? (uint32_t)rows16[row] : 0u; });
             if (dbg && !dbg2 && tid == 0) {
                 __builtin_amdgcn_s_waitcnt(0);
@@ -654,7 +662,7 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
             }
             return;
         }
-        float* out = p.obs + base;
+        float* out = obs_out + base;
         const int head = min(n, (int)((4 - (base & 3)) & 3));
         const uint32_t magic = p.w_magic;
         const int nvec = (n - head) >> 2;
@@ -740,14 +748,14 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
     // ---- phase 4: stream the observations, 16 bytes per lane per store ---------------------------------
     if (p.obs_u8) {
         const int nrows = nag * 3 * W;
-        stream_obs_u8(reinterpret_cast<uint8_t*>(p.obs), (size_t)env0 * A * 3 * W * W, nrows * W, W, p.w_magic, tid, NT,
+        stream_obs_u8(reinterpret_cast<uint8_t*>(obs_out), (size_t)env0 * A * 3 * W * W, nrows * W, W, p.w_magic, tid, NT,
                       p.store_policy == 1, [&](int row) -> uint32_t { return row < nrows ? s_rows[row] : 0u; });
         return;
     }
     {
         const int n = nag * 3 * W * W;  // floats written by this workgroup
         const size_t base = (size_t)env0 * A * 3 * W * W;
-        float* out = p.obs + base;
+        float* out = obs_out + base;
         const int head = min(n, (int)((4 - (base & 3)) & 3));
         const uint32_t magic = p.w_magic;  // ceil(2^32 / W)
         // unaligned head / tail (only when the workgroup's float count is not a multiple of 4)
@@ -781,6 +789,46 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
             __builtin_amdgcn_s_waitcnt(0);  // stores retired (vmcnt 0) before the end stamp
             p.dbg[(size_t)blk * 4 + 3] = wall_clock64();
         }
+    }
+}
+
+template <int G, bool MW, bool P16>
+__global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const StepParams p) {
+    const RolloutParams none{};
+    step_body<G, MW, P16, false>(p, none, 0, 0);
+}
+
+// K steps in ONE launch (pgx_rollout).  Environments never interact, so a workgroup can run its own environments
+// through all K steps without waiting for anybody else: step t of the launch reads actions[t] and writes the outputs
+// of slice t (observations: slot t % obs_slots).  Unlike K launches there is no launch boundary at which all waves
+// start their state phase together with HBM idle and finish together: after the first step the waves drift apart and
+// one wave's state phase runs under the other waves' observation streams.  Between two steps a wave waits for its own
+// stores (vmcnt counts loads and stores alike on gfx9, so the next step's loads could not be consumed earlier anyway):
+// that makes the state it wrote visible to its next iteration -- same CU, same vector L1; multi-wave workgroups add
+// the barrier.  Bit-identical with K pgx_step calls (tests/test_rollout_gpu.py).
+// The argument blocks are read through a kernarg pointer that is laundered once per iteration: otherwise LICM hoists
+// every argument load and every address computation of the (inlined) step out of the loop and the kernel needs > 100
+// VGPRs plus scratch where the single step needs < 50.
+template <int G, bool MW, bool P16>
+#ifndef PGX_ROLL_OCC
+#define PGX_ROLL_OCC 8
+#endif
+__global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : PGX_ROLL_OCC) void rollout_kernel(const StepParams p0, const RolloutParams rp0) {
+    typedef const __attribute__((address_space(4))) char KC;
+    typedef const __attribute__((address_space(4))) StepParams KP;
+    typedef const __attribute__((address_space(4))) RolloutParams KR;
+    constexpr size_t rp_offset = (sizeof(StepParams) + alignof(RolloutParams) - 1) / alignof(RolloutParams) * alignof(RolloutParams);
+    const int steps = rp0.steps, slots = rp0.obs_slots;
+    int slot = 0;
+    for (int t = 0; t < steps; ++t) {
+        KC* ka = (KC*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        KP& p = *reinterpret_cast<KP*>(ka);
+        KR& rp = *reinterpret_cast<KR*>(ka + rp_offset);
+        step_body<G, MW, P16, true>(p, rp, t, slot);
+        slot = slot + 1 == slots ? 0 : slot + 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (MW) __syncthreads();
     }
 }
 
@@ -982,10 +1030,19 @@ StepGeometry step_geometry(int batch, int A, int bmw, int W, bool allow_p16, int
 // once per handle (NOT per launch: keeps pgx_step capturable in a HIP graph).  The > 48 KB opt-in is an attribute of
 // the kernel FUNCTION on a device, not of a handle: two live handles may share a template instance with different LDS
 // needs, so the limit is only ever raised (largest request so far per function and device).
+static hipError_t raise_lds_limit(const void* fn, size_t lds_bytes);
+static const void* rollout_fn_for(const StepGeometry& g);
+
 hipError_t prepare_step(const StepGeometry& g) {
     const void* fn = step_fn_for(g);
-    if (!fn) return hipErrorInvalidValue;
-    if (g.lds_bytes <= 48 * 1024) return hipSuccess;
+    const void* rfn = rollout_fn_for(g);
+    if (!fn || !rfn) return hipErrorInvalidValue;
+    if (hipError_t e = raise_lds_limit(fn, g.lds_bytes)) return e;
+    return raise_lds_limit(rfn, g.lds_bytes);
+}
+
+static hipError_t raise_lds_limit(const void* fn, size_t lds_bytes) {
+    if (lds_bytes <= 48 * 1024) return hipSuccess;
     static std::mutex mu;
     static std::map<std::pair<const void*, int>, size_t> granted;
     int dev = 0;
@@ -993,10 +1050,33 @@ hipError_t prepare_step(const StepGeometry& g) {
     if (e != hipSuccess) return e;
     std::lock_guard<std::mutex> lock(mu);
     size_t& have = granted[{fn, dev}];
-    if (g.lds_bytes <= have) return hipSuccess;
-    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
-    if (e == hipSuccess) have = g.lds_bytes;
+    if (lds_bytes <= have) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e == hipSuccess) have = lds_bytes;
     return e;
+}
+
+template <int G, bool MW, bool P16>
+static const void* rollout_fn() { return reinterpret_cast<const void*>(&rollout_kernel<G, MW, P16>); }
+
+static const void* rollout_fn_for(const StepGeometry& g) {
+    if (g.multi_wave) return g.p16 ? rollout_fn<64, true, true>() : rollout_fn<64, true, false>();
+#define PGX_CASE(gg) case gg: return g.p16 ? rollout_fn<gg, false, true>() : rollout_fn<gg, false, false>();
+    switch (g.G) {
+        PGX_CASE(1) PGX_CASE(2) PGX_CASE(4) PGX_CASE(8) PGX_CASE(16) PGX_CASE(32) PGX_CASE(64)
+        default: return nullptr;
+    }
+#undef PGX_CASE
+}
+
+hipError_t launch_rollout(const StepParams& p, const RolloutParams& rp, const StepGeometry& g, hipStream_t stream) {
+    const void* fn = rollout_fn_for(g);
+    if (!fn) return hipErrorInvalidValue;
+    const int blocks = g.multi_wave ? p.batch : (p.batch + g.epw - 1) / g.epw;
+    StepParams args = p;
+    RolloutParams rargs = rp;
+    void* kargs[] = {&args, &rargs};
+    return hipLaunchKernel(fn, dim3(blocks), dim3(64 * g.waves), kargs, g.lds_bytes, stream);
 }
 
 hipError_t launch_step(const StepParams& p, const StepGeometry& g, hipStream_t stream) {

@@ -90,6 +90,8 @@ class VecPogema:
         if reuse_buffers not in (False, True, "single"):
             raise ValueError("reuse_buffers must be False, True or 'single'")
         self.single_buffer = reuse_buffers == "single"
+        self._rollout_pools = {}  # obs_slots -> ZoneBuffers of rollout()'s observation ring
+        self.placement = None     # how the reused observation buffers were placed (set on first use)
         self.reuse_buffers = bool(reuse_buffers)
         self.semantics = semantics if semantics is not None else Semantics.from_env()
         # placement probe of the double-buffered observation tensors (reuse_buffers=True); PGX_PLACEMENT=0 disables
@@ -459,6 +461,70 @@ class VecPogema:
                 raise IndexError(f"{bad} action(s) of active agents were outside 0..{len(self.grid_config.MOVES) - 1}")
         infos = {"is_active": is_active, "episode_done": self.episode_done, "metrics": self.metrics}
         return (self._wrap_obs(obs) if compute_obs else None), rewards, terminated, truncated, infos
+
+    def rollout(self, actions, obs_slots: Optional[int] = None):
+        """K steps in one launch (pgx_rollout): exactly `for t in range(K): step(actions[t])` -- same state afterwards,
+        same outputs -- for callers that have the actions up front (MAPF plans, scripted / random policies, replays).
+        `actions`: int tensor [K, batch, agents].  `obs_slots`: how many observation tensors to keep -- None = K (the whole
+        trajectory, K x obs bytes of HBM), n >= 1: a ring, step t lands in slot t % n (1 = only the last one), 0 = none.
+        A ring of up to 8 slots of >= 256 MiB each is taken from the engine's zone-spread buffers (`placement` as for
+        `reuse_buffers`), kept by the env and OVERWRITTEN BY THE NEXT rollout() with the same `obs_slots`; its first axis is
+        strided (slot stride = bytes rounded up to 2 MiB), every slot itself is contiguous.
+        Returns a dict of device tensors: obs [slots, batch, agents, 3, W, W] (or None), rewards f32 / terminated /
+        truncated / is_active bool [K, batch, agents], episode_done bool [K, batch], metrics f32 [K, batch, 6] (rows
+        where episode_done is set; ISR, CSR, ep_length, SoC, makespan, avg_throughput).  Observations are the raw
+        'default' tensor for every observation_type."""
+        if self.regenerate:
+            raise NotImplementedError("rollout() cannot draw new instances between its steps (auto_reset='regenerate')")
+        if not isinstance(actions, torch.Tensor):
+            actions = torch.as_tensor(np.asarray(actions))
+        if actions.dim() != 3 or tuple(actions.shape[1:]) != (self.batch, self.num_agents) or actions.shape[0] < 1:
+            raise ValueError(f"actions must have shape [K >= 1, {self.batch}, {self.num_agents}], got {tuple(actions.shape)}")
+        if actions.dtype not in self._ACTION_CODE:
+            actions = actions.to(torch.int64)
+        actions = actions.to(self.device).contiguous()
+        K = int(actions.shape[0])
+        slots = K if obs_slots is None else int(obs_slots)
+        if slots < 0:
+            raise ValueError("obs_slots must be >= 0")
+        slots = min(slots, K)
+        dev, BA = self.device, (K, self.batch, self.num_agents)
+        obs, slot_stride = None, 0
+        if slots:
+            obs_bytes = int(np.prod(self.obs_shape)) * (4 if self.obs_dtype == torch.float32 else 1)
+            if self.placement_probe and slots <= 8 and obs_bytes >= self.PLACEMENT_MIN_BYTES:
+                pool = self._rollout_pools.get(slots)
+                if pool is None:
+                    from .buffers import ZoneBuffers
+                    pool = self._rollout_pools[slots] = ZoneBuffers(self.obs_shape, self.obs_dtype, dev, count=slots)
+                    self.placement = dict(pool.info, method="pgx_buffers (two HBM zones per buffer)")
+                obs, slot_stride = pool.ring, pool.stride_bytes
+            else:
+                obs = torch.empty((slots,) + self.obs_shape, dtype=self.obs_dtype, device=dev)
+        out = {
+            "obs": obs,
+            "rewards": torch.empty(BA, dtype=torch.float32, device=dev),
+            "terminated": torch.empty(BA, dtype=torch.bool, device=dev),
+            "truncated": torch.empty(BA, dtype=torch.bool, device=dev),
+            "is_active": torch.empty(BA, dtype=torch.bool, device=dev),
+            "episode_done": torch.empty((K, self.batch), dtype=torch.bool, device=dev),
+            "metrics": torch.zeros((K, self.batch, 6), dtype=torch.float32, device=dev),
+        }
+        io = _lib.PgxRolloutIO(
+            actions=actions.data_ptr(), obs=out["obs"].data_ptr() if slots else None, rewards=out["rewards"].data_ptr(),
+            terminated=out["terminated"].data_ptr(), truncated=out["truncated"].data_ptr(),
+            is_active=out["is_active"].data_ptr(), episode_done=out["episode_done"].data_ptr(),
+            metrics=out["metrics"].data_ptr(), action_dtype=self._ACTION_CODE[actions.dtype], obs_slots=max(slots, 1),
+            obs_slot_stride=slot_stride)
+        import ctypes as C
+        _lib.check(self._lib.pgx_rollout(self._handle, K, C.byref(io), self._stream()))
+        if self.semantics.bad_action == "flag":
+            bad = int(self._lib.pgx_bad_action_count(self._handle, self._stream()))
+            if bad < 0:
+                _lib.check(bad)
+            if bad:
+                raise IndexError(f"{bad} action(s) of active agents were outside 0..{len(self.grid_config.MOVES) - 1}")
+        return out
 
     def set_targets(self, targets_xy, mask=None):
         """Overwrite current targets (int [batch, agents, 2], unpadded (row, col)) of the agents flagged in `mask`

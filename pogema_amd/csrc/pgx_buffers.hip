@@ -117,7 +117,12 @@ struct Range {
     void release() {
         for (Part& p : parts) drop_part(p);
         parts.clear();
-        if (va) (void)hipMemAddressFree(va, bytes);
+        // The address range itself is NOT given back (hipMemAddressFree): on ROCm 7.2 a range that is freed, reserved
+        // again at the same address and mapped to new memory can keep answering with its OLD translation -- stores that
+        // never arrive, then "Memory access fault by GPU" (tools/vmm_ring_repro.py: 2 of 2 runs within 6 pools; 0 of 36
+        // pools with the ranges kept).  Only address space leaks, <= ~0.3 TiB per zone walk out of 128 TiB.
+        // PGX_VA_FREE=1 restores the free (diagnostic).
+        if (va && getenv("PGX_VA_FREE")) (void)hipMemAddressFree(va, bytes);
         va = nullptr;
     }
 };

@@ -56,7 +56,8 @@ def _same_state(a, b):
 
 
 GEOMS = [  # (size, agents, radius, batch): G = 2, 8, 16, 64, multi-wave 128 agents, helper waves (small batch of big envs), generic rows (r = 9)
-    (8, 2, 3, 33), (16, 8, 5, 40), (32, 16, 5, 24), (64, 64, 5, 12), (40, 128, 4, 5), (64, 64, 5, 3), (24, 6, 9, 10)]
+    (8, 2, 3, 33), (16, 8, 5, 40), (32, 16, 5, 24), (64, 64, 5, 12), (40, 128, 4, 5), (64, 64, 5, 3), (24, 6, 9, 10),
+    (256, 256, 7, 3)]  # ... and the geometry of BASELINE configs[4]
 
 
 @pytest.mark.parametrize("size,agents,r,batch", GEOMS)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (under gpurun): rocprofv3 evidence for bench.py's workloads.
-#   1. --kernel-trace --stats of the bench command (without the extra default-placement window and the CPU baseline,
-#      which launch the same kernel on other buffers / burn host time)                       -> kernel_stats csv
+#   1. --kernel-trace --stats of the bench command (without the extra default-placement window, the secondary figures
+#      and the CPU baseline, which launch the same kernel on other buffers / batches or burn host time) -> kernel_stats csv
 #   2./3. separate --pmc passes (FETCH_SIZE, WRITE_SIZE; MI355X_MICROARCH.md "HBM")           -> per-launch counters
 #   4. counter calibration on tools/hbm_peak's known byte counts
 # usage: tools/collect_profiles.sh <outdir under gpurun_out> [workload ...]
@@ -12,7 +12,7 @@ WLS=${@:-cfg2}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for wl in $WLS; do
-  extra="--workload $wl --no-default-placement --no-cpu-baseline"
+  extra="--workload $wl --no-default-placement --no-cpu-baseline --no-extras"
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${wl}_stats -- python3 $R/bench.py $extra > $OUT/${wl}_bench.json 2> $OUT/${wl}_stats.err
   for ctr in FETCH_SIZE WRITE_SIZE; do
     # PGX_PLACEMENT=0: no zone walk (its probe kernels and spacers are irrelevant for per-launch traffic)

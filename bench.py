@@ -495,18 +495,27 @@ def main(argv=None):
     if (not args.stub and not args.no_extras and world == 1 and args.graph <= 0 and args.auto_reset == "restore"
             and not args.no_obs and args.buffers == 2):
         n = min(args.steps, 1000)
+        extra_errors = {}
         if batch % 2 == 0:
-            ps = PipelinedStep(args, rank, device, batch, env_base, size, agents, r)
-            extras["pipelined"] = {"engines": 2, "ms_per_step": ps.measure(n)}
-            ps.close()
-            del ps
+            try:  # a secondary figure must never cost the headline line
+                ps = PipelinedStep(args, rank, device, batch, env_base, size, agents, r)
+                extras["pipelined"] = {"engines": 2, "ms_per_step": ps.measure(n)}
+                ps.close()
+                del ps
+            except Exception as exc:  # noqa: BLE001
+                extra_errors["pipelined"] = repr(exc)
             torch.cuda.empty_cache()
-        rs = RolloutStep(args, rank, device, batch, env_base, size, agents, r)
-        extras["rollout"] = {"steps_per_launch": rs.k, "obs_slots": rs.slots, "ms_per_step": rs.measure(n),
-                             "placement_spread": bool((rs.env.placement or {}).get("spread", False))}
-        rs.close()
-        del rs
+        try:
+            rs = RolloutStep(args, rank, device, batch, env_base, size, agents, r)
+            extras["rollout"] = {"steps_per_launch": rs.k, "obs_slots": rs.slots, "ms_per_step": rs.measure(n),
+                                 "placement_spread": bool((rs.env.placement or {}).get("spread", False))}
+            rs.close()
+            del rs
+        except Exception as exc:  # noqa: BLE001
+            extra_errors["rollout"] = repr(exc)
         torch.cuda.empty_cache()
+        if extra_errors:
+            extras["errors"] = extra_errors
 
     if rank == 0:
         n_agent_steps = total_envs * agents * args.steps

@@ -197,7 +197,10 @@ int pgx_step(pgx_env* env, const void* actions, int action_dtype, void* obs, flo
  * episodes): upstream, the `for t in range(K): env.step(actions[t])` loop around `Pogema.step`.  Every workgroup takes its
  * own environments through all K steps, so there is no launch boundary between steps and one wave's collision resolve
  * runs under the other waves' observation streams.  All pointers are device pointers.
- *   actions       [steps, batch, agents] of action_dtype
+ *   actions       [steps, batch, agents] of action_dtype, or NULL: the engine's uniform random policy -- action
+ *                 (h >> 32) * 5 >> 32 of a splitmix64 chain over (policy_seed, cfg.env_index_base + env, agent,
+ *                 policy_step0 + t), the same whatever the sharding; written to actions_out ([steps, batch, agents] i8)
+ *                 when that is not NULL
  *   obs           [obs_slots, batch, agents, 3, 2r+1, 2r+1] f32 (u8 with PGX_OBS_U8) or NULL; step t writes slot
  *                 t % obs_slots: obs_slots = steps keeps the whole trajectory, 1 only the last observation.
  *                 obs_slot_stride: bytes from one slot to the next; 0 = dense.  (pgx_buffers_stride() for a ring made
@@ -221,6 +224,9 @@ typedef struct pgx_rollout_io {
     int32_t action_dtype;
     int32_t obs_slots;
     int64_t obs_slot_stride;
+    uint64_t policy_seed;
+    int64_t policy_step0;
+    int8_t* actions_out;
 } pgx_rollout_io;
 int pgx_rollout(pgx_env* env, int32_t steps, const pgx_rollout_io* io, void* stream);
 

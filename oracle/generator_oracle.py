@@ -181,3 +181,16 @@ def generate_instance_numpy(seed, height, width, num_agents, density, given_map=
     if len(finishes_xy) < num_agents:
         raise OverflowError(f"only {len(finishes_xy)} of {num_agents} start/target pairs can be placed")
     return obstacles.astype(np.uint8), np.array(positions_xy, np.int32), np.array(finishes_xy, np.int32)
+
+
+def policy_action(seed: int, env: int, agent: int, step: int) -> int:
+    """The engine's uniform random policy (pgx_rollout with actions = NULL; pgx_kernels.hip: policy_action)."""
+    h = splitmix64((seed ^ 0x504F4C4943590000) & _MASK64)
+    h = splitmix64(h ^ (env & _MASK64))
+    h = splitmix64(h ^ (((step << 20) | agent) & _MASK64))
+    return ((h >> 32) * 5) >> 32
+
+
+def policy_actions(seed: int, env_index_base: int, batch: int, agents: int, step0: int, steps: int) -> np.ndarray:
+    return np.array([[[policy_action(seed, env_index_base + b, a, step0 + t) for a in range(agents)] for b in range(batch)]
+                     for t in range(steps)], dtype=np.int8)

@@ -70,7 +70,8 @@ class PgxBuffersInfo(C.Structure):
 class PgxRolloutIO(C.Structure):
     _fields_ = [("actions", C.c_void_p), ("obs", C.c_void_p), ("rewards", C.c_void_p), ("terminated", C.c_void_p),
                 ("truncated", C.c_void_p), ("is_active", C.c_void_p), ("episode_done", C.c_void_p), ("metrics", C.c_void_p),
-                ("action_dtype", C.c_int32), ("obs_slots", C.c_int32), ("obs_slot_stride", C.c_int64)]
+                ("action_dtype", C.c_int32), ("obs_slots", C.c_int32), ("obs_slot_stride", C.c_int64),
+                ("policy_seed", C.c_uint64), ("policy_step0", C.c_int64), ("actions_out", C.c_void_p)]
 
 
 class PgxConfig(C.Structure):

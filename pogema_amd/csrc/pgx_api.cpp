@@ -622,8 +622,10 @@ int pgx_step(pgx_env* e, const void* actions, int action_dtype, void* obs, float
 }
 
 int pgx_rollout(pgx_env* e, int32_t steps, const pgx_rollout_io* io, void* stream) {
-    if (!e || !io || !io->actions || !io->rewards || !io->terminated || !io->truncated)
+    if (!e || !io || !io->rewards || !io->terminated || !io->truncated)
         return fail(PGX_E_INVALID, "pgx_rollout: null argument");
+    if (io->policy_step0 < 0 || io->policy_step0 > ((int64_t)1 << 40))
+        return fail(PGX_E_INVALID, "pgx_rollout: policy_step0 outside 0..2^40");
     if (steps < 1) return fail(PGX_E_INVALID, "pgx_rollout: steps must be >= 1, got %d", steps);
     if (io->action_dtype < 0 || io->action_dtype > 2) return fail(PGX_E_INVALID, "pgx_rollout: bad action_dtype %d", io->action_dtype);
     if (io->obs && io->obs_slots < 1) return fail(PGX_E_INVALID, "pgx_rollout: obs given but obs_slots = %d", io->obs_slots);
@@ -652,6 +654,9 @@ int pgx_rollout(pgx_env* e, int32_t steps, const pgx_rollout_io* io, void* strea
     rp.agents_stride = agents;
     rp.envs_stride = e->cfg.batch;
     rp.obs_stride = agents * 3 * W * W * (p.obs_u8 ? 1 : 4);
+    rp.policy_seed = io->policy_seed;
+    rp.policy_step0 = io->policy_step0;
+    rp.actions_out = io->actions ? nullptr : io->actions_out;
     if (io->obs && io->obs_slot_stride != 0) {
         if (io->obs_slot_stride < rp.obs_stride || (io->obs_slot_stride & 15) != 0)
             return fail(PGX_E_INVALID, "pgx_rollout: obs_slot_stride %lld is smaller than one observation tensor (%lld bytes) or not a multiple of 16",

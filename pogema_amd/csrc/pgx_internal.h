@@ -112,6 +112,9 @@ struct RolloutParams {
     int64_t agents_stride;    // batch * num_agents: elements between per-agent outputs of consecutive steps
     int64_t envs_stride;      // batch: elements between per-env outputs of consecutive steps
     int64_t obs_stride;       // bytes between observation slots
+    uint64_t policy_seed;     // actions == NULL: uniform random policy keyed by (policy_seed, global env, agent, policy_step0 + t)
+    int64_t policy_step0;
+    int8_t* actions_out;      // [steps, batch, agents] the policy's actions (may be null)
 };
 
 // How one configuration maps onto the step kernel (pgx_kernels.hip: step_geometry()).

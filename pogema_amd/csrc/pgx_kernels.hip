@@ -45,6 +45,15 @@ __device__ __forceinline__ uint32_t lifelong_draw(uint64_t seed, uint64_t env_in
     return (uint32_t)(((h >> 32) * (uint64_t)n) >> 32);
 }
 
+// pgx_rollout without an action tensor: the uniform random policy, action in 0..4 for (seed, global env, agent, step).
+// Stated in oracle/generator_oracle.py (policy_action); tests/test_rollout_gpu.py.
+__device__ __forceinline__ int policy_action(uint64_t seed, uint64_t env_index, uint32_t agent, uint64_t step) {
+    uint64_t h = splitmix64(seed ^ 0x504F4C4943590000ull);  // 'POLICY'
+    h = splitmix64(h ^ env_index);
+    h = splitmix64(h ^ (step << 20 | (uint64_t)agent));
+    return (int)(((h >> 32) * 5ull) >> 32);
+}
+
 __device__ __forceinline__ pgxnp::Pcg64 np_unpack(const NpGen& s) {
     pgxnp::Pcg64 g;
     g.state = ((pgxnp::u128)s.w[0] << 64) | s.w[1];
@@ -318,7 +327,11 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
         active = p.active[gi] != 0;
         if (p.mode == MODE_STEP) {
             const size_t ai = ROLL ? gi + (size_t)t * (size_t)rp.agents_stride : gi;
-            if (p.action_dtype == 0) act = ((const int8_t*)p.actions)[ai];
+            if (ROLL && p.actions == nullptr) {  // the engine's own uniform random policy
+                act = policy_action((uint64_t)rp.policy_seed, (uint64_t)(p.env_index_base + env), (uint32_t)agent,
+                                    (uint64_t)(rp.policy_step0 + t));
+                if (rp.actions_out) rp.actions_out[ai] = (int8_t)act;
+            } else if (p.action_dtype == 0) act = ((const int8_t*)p.actions)[ai];
             else if (p.action_dtype == 1) act = ((const int32_t*)p.actions)[ai];
             else act = (int)((const int64_t*)p.actions)[ai];
         }

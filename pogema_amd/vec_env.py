@@ -462,7 +462,8 @@ class VecPogema:
         infos = {"is_active": is_active, "episode_done": self.episode_done, "metrics": self.metrics}
         return (self._wrap_obs(obs) if compute_obs else None), rewards, terminated, truncated, infos
 
-    def rollout(self, actions, obs_slots: Optional[int] = None):
+    def rollout(self, actions=None, obs_slots: Optional[int] = None, steps: Optional[int] = None, policy_seed: int = 0,
+                policy_step0: int = 0, record_actions: bool = True):
         """K steps in one launch (pgx_rollout): exactly `for t in range(K): step(actions[t])` -- same state afterwards,
         same outputs -- for callers that have the actions up front (MAPF plans, scripted / random policies, replays).
         `actions`: int tensor [K, batch, agents].  `obs_slots`: how many observation tensors to keep -- None = K (the whole
@@ -473,17 +474,29 @@ class VecPogema:
         Returns a dict of device tensors: obs [slots, batch, agents, 3, W, W] (or None), rewards f32 / terminated /
         truncated / is_active bool [K, batch, agents], episode_done bool [K, batch], metrics f32 [K, batch, 6] (rows
         where episode_done is set; ISR, CSR, ep_length, SoC, makespan, avg_throughput).  Observations are the raw
-        'default' tensor for every observation_type."""
+        'default' tensor for every observation_type.
+
+        `actions=None, steps=K`: the engine's own uniform random policy (data collection, benchmarks): the action of
+        (policy_seed, global env, agent, policy_step0 + t) is a fixed hash, the same however the batch is sharded;
+        `record_actions` returns them as out['actions'] (int8 [K, batch, agents]).  Continue a run with
+        policy_step0 += K."""
         if self.regenerate:
             raise NotImplementedError("rollout() cannot draw new instances between its steps (auto_reset='regenerate')")
-        if not isinstance(actions, torch.Tensor):
-            actions = torch.as_tensor(np.asarray(actions))
-        if actions.dim() != 3 or tuple(actions.shape[1:]) != (self.batch, self.num_agents) or actions.shape[0] < 1:
-            raise ValueError(f"actions must have shape [K >= 1, {self.batch}, {self.num_agents}], got {tuple(actions.shape)}")
-        if actions.dtype not in self._ACTION_CODE:
-            actions = actions.to(torch.int64)
-        actions = actions.to(self.device).contiguous()
-        K = int(actions.shape[0])
+        if actions is None:
+            if steps is None or int(steps) < 1:
+                raise ValueError("rollout(actions=None) needs steps >= 1")
+            K = int(steps)
+        else:
+            if not isinstance(actions, torch.Tensor):
+                actions = torch.as_tensor(np.asarray(actions))
+            if actions.dim() != 3 or tuple(actions.shape[1:]) != (self.batch, self.num_agents) or actions.shape[0] < 1:
+                raise ValueError(f"actions must have shape [K >= 1, {self.batch}, {self.num_agents}], got {tuple(actions.shape)}")
+            if steps is not None and int(steps) != int(actions.shape[0]):
+                raise ValueError("steps does not match actions.shape[0]")
+            if actions.dtype not in self._ACTION_CODE:
+                actions = actions.to(torch.int64)
+            actions = actions.to(self.device).contiguous()
+            K = int(actions.shape[0])
         slots = K if obs_slots is None else int(obs_slots)
         if slots < 0:
             raise ValueError("obs_slots must be >= 0")
@@ -510,12 +523,16 @@ class VecPogema:
             "episode_done": torch.empty((K, self.batch), dtype=torch.bool, device=dev),
             "metrics": torch.zeros((K, self.batch, 6), dtype=torch.float32, device=dev),
         }
+        if actions is None and record_actions:
+            out["actions"] = torch.empty(BA, dtype=torch.int8, device=dev)
         io = _lib.PgxRolloutIO(
-            actions=actions.data_ptr(), obs=out["obs"].data_ptr() if slots else None, rewards=out["rewards"].data_ptr(),
+            actions=actions.data_ptr() if actions is not None else None, obs=out["obs"].data_ptr() if slots else None,
+            rewards=out["rewards"].data_ptr(),
             terminated=out["terminated"].data_ptr(), truncated=out["truncated"].data_ptr(),
             is_active=out["is_active"].data_ptr(), episode_done=out["episode_done"].data_ptr(),
-            metrics=out["metrics"].data_ptr(), action_dtype=self._ACTION_CODE[actions.dtype], obs_slots=max(slots, 1),
-            obs_slot_stride=slot_stride)
+            metrics=out["metrics"].data_ptr(), action_dtype=self._ACTION_CODE[actions.dtype] if actions is not None else 0,
+            obs_slots=max(slots, 1), obs_slot_stride=slot_stride, policy_seed=int(policy_seed) & 0xFFFFFFFFFFFFFFFF,
+            policy_step0=int(policy_step0), actions_out=out["actions"].data_ptr() if "actions" in out else None)
         import ctypes as C
         _lib.check(self._lib.pgx_rollout(self._handle, K, C.byref(io), self._stream()))
         if self.semantics.bad_action == "flag":

@@ -66,7 +66,7 @@ def test_lds_limit_is_reported(engine_lib):
 def test_buffers_info_struct_layout():
     # struct pgx_buffers_info: int64, 4 x int32, 2 x float, double, 2 x float
     assert C.sizeof(_lib.PgxBuffersInfo) == 8 + 16 + 8 + 8 + 8
-    assert C.sizeof(_lib.PgxRolloutIO) == 8 * 8 + 4 + 4 + 8  # pgx_rollout_io
+    assert C.sizeof(_lib.PgxRolloutIO) == 8 * 8 + 4 + 4 + 8 + 8 + 8 + 8  # pgx_rollout_io
     assert _lib.PgxBuffersInfo.same_zone_us.offset == 24 and _lib.PgxBuffersInfo.spacer_gib.offset == 32
     assert _lib.PgxBuffersInfo.buffer_gbs.offset == 40
 

@@ -147,3 +147,33 @@ def test_rollout_full_size_headline_shape():
     a, b, ref, got = _pair(gc, 8192, 6, obs_slots=2, auto_reset=True)
     _same(ref, got, 6, obs_slots=2)
     _same_state(a, b)
+
+
+def test_random_policy_rollout():
+    """actions=None: the recorded actions are the stated hash, the rollout equals a rollout (and a step loop) fed with
+    them, the stream does not depend on how the batch is sharded, and policy_step0 continues it."""
+    from oracle.generator_oracle import policy_actions
+    B, A, K = 12, 8, 20
+    gc = GridConfig(size=16, num_agents=A, obs_radius=3, density=0.2, max_episode_steps=8, seed=4, collision_system="soft")
+    a = VecPogema(gc, batch=B, device=DEV, auto_reset=True, env_index_base=100)
+    b = VecPogema(gc, batch=B, device=DEV, auto_reset=True, env_index_base=100)
+    a.reset(seed=1)
+    b.reset(seed=1)
+    got = a.rollout(steps=K, policy_seed=77, policy_step0=5)
+    acts = got["actions"]
+    np.testing.assert_array_equal(acts.cpu().numpy(), policy_actions(77, 100, B, A, 5, K))
+    assert set(np.unique(acts.cpu().numpy())) == {0, 1, 2, 3, 4}
+    ref = b.rollout(acts)
+    for k in ("obs", "rewards", "terminated", "truncated", "is_active", "episode_done", "metrics"):
+        assert torch.equal(ref[k], got[k]), k
+    _same_state(a, b)
+    # second half of the batch as its own shard: same actions for the same global envs; continuation by policy_step0
+    c = VecPogema(gc, batch=B // 2, device=DEV, auto_reset=True, env_index_base=100 + B // 2)
+    c.reset(seed=1)
+    part = c.rollout(steps=K, policy_seed=77, policy_step0=5, obs_slots=0)
+    assert torch.equal(part["actions"], acts[:, B // 2:])
+    assert torch.equal(part["rewards"], got["rewards"][:, B // 2:])
+    more = a.rollout(steps=3, policy_seed=77, policy_step0=5 + K, obs_slots=1)
+    np.testing.assert_array_equal(more["actions"].cpu().numpy(), policy_actions(77, 100, B, A, 5 + K, 3))
+    with pytest.raises(ValueError):
+        a.rollout()

@@ -230,7 +230,9 @@ class EngineStep:
             return (f"{self.nbuf} alternating buffers from the engine's zone-aware pool: halves in two HBM zones = {pl['spread']} "
                     f"(probe stream {pl['same_zone_us']:.1f} us same-zone -> {pl['final_us']:.1f} us as placed, "
                     f"{pl['candidates']} candidates, {pl['spacer_gib']:.0f} GiB of temporary spacers; plain store stream "
-                    f"into the slowest buffer: {pl['buffer_gbs']:.0f} GB/s)")
+                    f"into the slowest buffer: {pl['buffer_gbs']:.0f} GB/s); observation stream timed into them "
+                    f"{pl.get('observe_us_zone')} us vs best of torch's own buffers {pl.get('observe_us_torch_best')} us -> "
+                    f"kept {pl.get('chosen')} at {pl.get('observe_us')} us")
         return f"{self.nbuf} output buffer(s) as torch's allocator returned them (no zone placement)"
 
     def box_store_stream_gbs(self):

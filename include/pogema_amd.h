@@ -299,6 +299,9 @@ int pgx_buffers_create(int device, size_t bytes, int count, double max_spacer_gi
 void* pgx_buffers_ptr(pgx_buffers* pool, int index); /* device pointer of buffer `index`, NULL if out of range */
 int64_t pgx_buffers_stride(pgx_buffers* pool);       /* all buffers lie in ONE virtual range: ptr(i) = ptr(0) + i * stride,
                                                         stride = bytes rounded up to 2 MiB (pgx_rollout_io.obs_slot_stride) */
+int pgx_buffers_drop(pgx_buffers* pool, int index);  /* releases the memory of ONE buffer (its addresses stay reserved and
+                                                        must not be touched again): a caller may ask for more buffers
+                                                        than it needs, time its own stream into each and keep the best */
 int pgx_buffers_get_info(pgx_buffers* pool, pgx_buffers_info* info);
 int pgx_buffers_destroy(pgx_buffers* pool);          /* synchronises the device, then unmaps and frees        */
 

@@ -84,7 +84,24 @@ class ZoneBuffers:
         dense = [item]
         for n in reversed(tuple(shape)[1:]):
             dense.insert(0, dense[0] * n)
-        self.ring = torch.as_tensor(_Cai(lib.pgx_buffers_ptr(handle, 0), (count,) + tuple(shape), _TYPESTR[dtype], self._owner,
-                                         strides=(self.stride_bytes,) + tuple(dense)), device=torch.device("cuda", index))
-        if self.ring.data_ptr() != self.tensors[0].data_ptr() or self.ring.stride(0) * item != self.stride_bytes:
+        self._lib, self._handle = lib, handle
+        self._view = (tuple(shape), _TYPESTR[dtype], tuple(dense), item, torch.device("cuda", index))
+        self.ring = self.ring_view(0, count)
+
+    def ring_view(self, start: int, count: int) -> torch.Tensor:
+        """Buffers start .. start+count-1 as one [count, *shape] tensor (first axis strided by `stride_bytes`)."""
+        shape, typestr, dense, item, dev = self._view
+        ptr = self._lib.pgx_buffers_ptr(self._handle, int(start))
+        if not ptr or start + count > len(self.tensors):
+            raise IndexError("ring_view outside the pool")
+        ring = torch.as_tensor(_Cai(ptr, (count,) + shape, typestr, self._owner, strides=(self.stride_bytes,) + dense), device=dev)
+        if ring.data_ptr() != ptr or ring.stride(0) * item != self.stride_bytes:
             raise RuntimeError("torch copied the zone buffers instead of wrapping them")
+        return ring
+
+    def drop(self, index: int):
+        """Release the memory of buffer `index` (pgx_buffers_drop).  The caller must have dropped every reference to
+        `tensors[index]`; `ring` is no longer usable as a whole afterwards."""
+        self.tensors[index] = None
+        self.ring = None
+        _lib.check(self._lib.pgx_buffers_drop(self._handle, int(index)))

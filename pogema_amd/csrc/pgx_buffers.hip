@@ -211,6 +211,7 @@ void find_other_zone(int device, size_t budget, std::vector<Range>& held, pgx_bu
     }
     size_t spacer_bytes = 0;
     int weak_run = 0;
+    bool prev_strong = false;
     while (spacer_bytes + SPACER <= budget) {
         held.emplace_back();
         if (make_chunk(device, SPACER, held.back()) != hipSuccess) { held.pop_back(); (void)hipGetLastError(); break; }
@@ -232,23 +233,14 @@ void find_other_zone(int device, size_t budget, std::vector<Range>& held, pgx_bu
         if (weak && !strong) weak_run += 1;
         else if (t >= 0.97f * t_same && weak_run > 0) weak_run = WEAK_LIMIT;  // left it without finding better: take the next one
         const bool last = spacer_bytes + 2 * SPACER > budget;
-        if (!getenv("PGX_ZONE_SCAN") && (strong || (weak && (weak_run > WEAK_LIMIT || last)))) {
+        // A strong candidate may itself straddle the boundary, and fast stretches narrower than a spacer exist: it
+        // takes a second strong candidate, one spacer further, to accept (what is allocated next then lies inside the
+        // zone); a lone one is walked past.
+        const bool confirmed = strong && (prev_strong || last);
+        prev_strong = strong;
+        if (!getenv("PGX_ZONE_SCAN") && (confirmed || (weak && !strong && (weak_run > WEAK_LIMIT || last)))) {
             info.final_us = t;
             *found = true;
-            // the first faster candidate may itself straddle the boundary: one more spacer puts what is allocated
-            // next safely inside the new zone (zones are tens of GiB wide)
-            if (spacer_bytes + SPACER <= budget) {
-                held.emplace_back();
-                if (make_chunk(device, SPACER, held.back()) != hipSuccess) { held.pop_back(); (void)hipGetLastError(); return; }
-                spacer_bytes += SPACER;
-                info.spacer_gib = (double)spacer_bytes / (double)GiB;
-                held.emplace_back();
-                if (make_chunk(device, PROBE_HALF, held.back()) != hipSuccess) { held.pop_back(); (void)hipGetLastError(); return; }
-                if (probe_us(ref, held.back().va, PROBE_HALF, &t) == hipSuccess) {
-                    info.candidates += 1;
-                    info.final_us = t;
-                }
-            }
             return;
         }
     }
@@ -345,6 +337,18 @@ void* pgx_buffers_ptr(pgx_buffers* p, int index) {
 }
 
 int64_t pgx_buffers_stride(pgx_buffers* p) { return p ? (int64_t)p->stride : 0; }
+
+int pgx_buffers_drop(pgx_buffers* p, int index) {
+    if (!p || index < 0 || index >= p->count) return pgx::fail_msg(PGX_E_INVALID, "pgx_buffers_drop: bad argument");
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(p->device);
+    (void)hipDeviceSynchronize();  // nothing may still be writing into the buffer
+    drop_part(p->all.parts[(size_t)2 * index]);
+    drop_part(p->all.parts[(size_t)2 * index + 1]);
+    if (prev >= 0) (void)hipSetDevice(prev);
+    return PGX_OK;
+}
 
 int pgx_buffers_get_info(pgx_buffers* p, pgx_buffers_info* info) {
     if (!p || !info) return pgx::fail_msg(PGX_E_INVALID, "pgx_buffers_get_info: null argument");

@@ -375,9 +375,50 @@ class VecPogema:
             self.placement = {"spread": False, "method": "torch allocator"}
             return [torch.empty(self.obs_shape, dtype=self.obs_dtype, device=self.device) for _ in range(n)]
         from .buffers import ZoneBuffers
-        pool = ZoneBuffers(self.obs_shape, self.obs_dtype, self.device, count=n)
+        # The walk's verdict does not always carry over to the real buffers (halves may straddle a boundary), and some
+        # boxes show no zones at all: ask the pool for two buffers more than needed, time the observation stream itself
+        # into each of them and into a few buffers as torch's allocator hands them out, keep the fastest n and give
+        # the rest back.
+        spare = self.SPARE_BUFFERS if self._has_state() else 0
+        pool = ZoneBuffers(self.obs_shape, self.obs_dtype, self.device, count=n + spare)
         self.placement = dict(pool.info, method="pgx_buffers (two HBM zones per buffer)")
-        return pool.tensors
+        cands = [(self._time_observe(t), i, "zone", t) for i, t in enumerate(pool.tensors)]
+        if self._has_state():
+            k = self.PLAIN_CANDIDATES if obs_bytes < (1 << 30) else self.PLAIN_CANDIDATES // 2
+            plain = [torch.empty(self.obs_shape, dtype=self.obs_dtype, device=self.device) for _ in range(k)]
+            cands += [(self._time_observe(t), n + i, "torch", t) for i, t in enumerate(plain)]
+            del plain
+        cands.sort(key=lambda c: (c[0], c[1]))
+        # a plain buffer replaces a pool buffer only when it is clearly faster (2 %): equal times keep the pool
+        zone = [c for c in cands if c[2] == "zone"]
+        other = [c for c in cands if c[2] != "zone"]
+        chosen = zone[:n]
+        for c in other:
+            worst = max(chosen, key=lambda z: z[0])
+            if c[0] < 0.98 * worst[0]:
+                chosen[chosen.index(worst)] = c
+        self.placement.update(chosen=[c[2] for c in chosen], observe_us=[round(c[0], 1) for c in chosen],
+                              observe_us_zone=[round(c[0], 1) for c in zone],
+                              observe_us_torch_best=round(min((c[0] for c in other), default=0.0), 1))
+        kept = {c[1] for c in chosen if c[2] == "zone"}
+        result = [c[3] for c in chosen]
+        del cands, other, zone, chosen
+        for i in range(n + spare):
+            if i not in kept:
+                pool.drop(i)
+        torch.cuda.empty_cache()
+        return result
+
+    PLAIN_CANDIDATES = 8
+    SPARE_BUFFERS = 4
+
+    def _time_observe(self, obs: torch.Tensor) -> float:
+        """Average duration [us] of the observation stream into `obs` (pgx_time_observe; needs an installed state)."""
+        if not self._has_state():
+            return 0.0
+        us = C.c_float(0.0)
+        _lib.check(self._lib.pgx_time_observe(self._handle, obs.data_ptr(), 3, C.byref(us), self._stream()))
+        return float(us.value)
 
     def _has_state(self):
         return self._initial is not None
@@ -506,12 +547,23 @@ class VecPogema:
         if slots:
             obs_bytes = int(np.prod(self.obs_shape)) * (4 if self.obs_dtype == torch.float32 else 1)
             if self.placement_probe and slots <= 8 and obs_bytes >= self.PLACEMENT_MIN_BYTES:
-                pool = self._rollout_pools.get(slots)
-                if pool is None:
+                entry = self._rollout_pools.get(slots)
+                if entry is None:
+                    # two buffers more than needed; the run of `slots` consecutive ones into which the observation
+                    # stream itself is fastest becomes the ring, the others are given back (see _pick_obs_buffers)
                     from .buffers import ZoneBuffers
-                    pool = self._rollout_pools[slots] = ZoneBuffers(self.obs_shape, self.obs_dtype, dev, count=slots)
-                    self.placement = dict(pool.info, method="pgx_buffers (two HBM zones per buffer)")
-                obs, slot_stride = pool.ring, pool.stride_bytes
+                    pool = ZoneBuffers(self.obs_shape, self.obs_dtype, dev, count=slots + 2)
+                    times = [self._time_observe(t) for t in pool.tensors]
+                    start = min(range(3), key=lambda s: (max(times[s:s + slots]), s))
+                    ring = pool.ring_view(start, slots)
+                    for i in range(slots + 2):
+                        if not start <= i < start + slots:
+                            pool.drop(i)
+                    entry = self._rollout_pools[slots] = (pool, ring)
+                    self.placement = dict(pool.info, method="pgx_buffers (two HBM zones per buffer)",
+                                          observe_us=[round(t, 1) for t in times[start:start + slots]],
+                                          observe_us_zone=[round(t, 1) for t in times])
+                obs, slot_stride = entry[1], entry[0].stride_bytes
             else:
                 obs = torch.empty((slots,) + self.obs_shape, dtype=self.obs_dtype, device=dev)
         out = {

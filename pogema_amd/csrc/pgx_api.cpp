@@ -83,7 +83,8 @@ int next_pow2(int v) {
 struct pgx_env {
     pgx_config cfg{};
     int device = 0;
-    pgx::StepGeometry geo{};
+    pgx::StepGeometry geo{};       // launch shape of pgx_step / pgx_observe
+    pgx::StepGeometry geo_roll{};  // ... of pgx_rollout
     int W = 0, PH = 0, PW = 0, wpr = 0, bmw = 0;
     bool has_state = false;
     uint32_t flags = 0;
@@ -161,15 +162,21 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
     if (const char* f = getenv("PGX_WAVES")) waves_override = atoi(f);
     e->geo = pgx::step_geometry(cfg->batch, A, e->bmw, e->W, !(e->flags & 2u), epw_override,
                                 cfg->obs_dtype == PGX_OBS_U8 ? 1 : 4, waves_override);
-    if (const char* f = getenv("PGX_STAGGER")) e->geo.stagger = atoi(f);  // tuning/diagnostic override
-    if (const char* f = getenv("PGX_STORE")) {  // tuning/diagnostic override: plain | nt | sc1
-        const std::string v = f;
-        e->geo.store_policy = v == "plain" ? 0 : v == "nt" ? 1 : v == "sc1" ? 2 : e->geo.store_policy;
+    // pgx_rollout's launch shape: the same, minus the helper waves of large launches (step_geometry())
+    e->geo_roll = pgx::step_geometry(cfg->batch, A, e->bmw, e->W, !(e->flags & 2u), epw_override,
+                                     cfg->obs_dtype == PGX_OBS_U8 ? 1 : 4, waves_override, true);
+    for (pgx::StepGeometry* g : {&e->geo, &e->geo_roll}) {
+        if (const char* f = getenv("PGX_STAGGER")) g->stagger = atoi(f);  // tuning/diagnostic override
+        if (const char* f = getenv("PGX_STORE")) {  // tuning/diagnostic override: plain | nt | sc1
+            const std::string v = f;
+            g->store_policy = v == "plain" ? 0 : v == "nt" ? 1 : v == "sc1" ? 2 : g->store_policy;
+        }
+        if (const char* f = getenv("PGX_LDS_MIN")) {  // diagnostic: cap residency by reserving LDS per workgroup
+            const size_t m = (size_t)atol(f);
+            if (m > g->lds_bytes) g->lds_bytes = (m + 15) & ~(size_t)15;
+        }
     }
-    if (const char* f = getenv("PGX_LDS_MIN")) {  // diagnostic: cap residency by reserving LDS per workgroup
-        const size_t m = (size_t)atol(f);
-        if (m > e->geo.lds_bytes) e->geo.lds_bytes = (m + 15) & ~(size_t)15;
-    }
+    if (e->geo_roll.lds_bytes > e->geo.lds_bytes && e->geo_roll.lds_bytes > 160 * 1024) e->geo_roll = e->geo;
     if (e->geo.lds_bytes > 160 * 1024) {
         const size_t need = e->geo.lds_bytes;
         delete e;
@@ -225,7 +232,7 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
     if (err == hipSuccess && e->np_state0)
         err = pgx::launch_init_np_lifelong(e->np_state0, cfg->seed, cfg->env_index_base, cfg->batch, A, nullptr);
     if (err == hipSuccess && e->np_state0) err = hipStreamSynchronize(nullptr);
-    if (err == hipSuccess) err = pgx::prepare_step(e->geo);
+    if (err == hipSuccess) err = pgx::prepare_step(e->geo, e->geo_roll);
     if (err != hipSuccess) {
         const char* msg = hipGetErrorString(err);
         const size_t need = e->geo.lds_bytes;
@@ -663,7 +670,10 @@ int pgx_rollout(pgx_env* e, int32_t steps, const pgx_rollout_io* io, void* strea
                         (long long)io->obs_slot_stride, (long long)rp.obs_stride);
         rp.obs_stride = io->obs_slot_stride;
     }
-    PGX_HIP(pgx::launch_rollout(p, rp, e->geo, (hipStream_t)stream));
+    p.epw = e->geo_roll.epw;
+    p.stagger = e->geo_roll.stagger;
+    p.store_policy = e->geo_roll.store_policy;
+    PGX_HIP(pgx::launch_rollout(p, rp, e->geo_roll, (hipStream_t)stream));
     return PGX_OK;
 }
 

@@ -129,8 +129,8 @@ struct StepGeometry {
     size_t lds_bytes;
 };
 StepGeometry step_geometry(int batch, int A, int bmw, int W, bool allow_p16, int epw_override, int obs_elem_bytes,
-                           int waves_override);
-hipError_t prepare_step(const StepGeometry& g);
+                           int waves_override, bool for_rollout = false);
+hipError_t prepare_step(const StepGeometry& g, const StepGeometry& roll);
 hipError_t launch_step(const StepParams& p, const StepGeometry& g, hipStream_t stream);
 hipError_t launch_rollout(const StepParams& p, const RolloutParams& rp, const StepGeometry& g, hipStream_t stream);
 

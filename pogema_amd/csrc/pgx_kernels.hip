@@ -211,7 +211,7 @@ __device__ __forceinline__ void store_obs16(f32x4_t* ptr, f32x4_t v, uint32_t po
 // ((x * 0x204081) & 0x01010101: bit i lands on bit 8i, no two partial products share a bit).
 template <typename RowBits>
 __device__ __forceinline__ void stream_obs_u8(uint8_t* out, size_t base, int n, int W, uint32_t magic, int tid, int NT,
-                                              bool nontemporal, RowBits row_bits) {
+                                              bool nontemporal, RowBits row_bits, int wave = 0, int nw = 1) {
     uint8_t* o = out + base;
     const int head = min(n, (int)((16 - (base & 15)) & 15));
     const int nvec = (n - head) >> 4;
@@ -226,7 +226,11 @@ __device__ __forceinline__ void stream_obs_u8(uint8_t* out, size_t base, int n, 
     }
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     u32x4* out4 = reinterpret_cast<u32x4*>(o + head);
-    for (int q = tid; q < nvec; q += NT) {
+    // nw > 1: every wave streams its own contiguous part (see wave_span)
+    const int part = (nvec + nw - 1) / nw;
+    const int q0 = nw > 1 ? wave * part + (tid & 63) : tid, q1 = nw > 1 ? min(nvec, (wave + 1) * part) : nvec;
+    const int qs = nw > 1 ? 64 : NT;
+    for (int q = q0; q < q1; q += qs) {
         const int e0 = head + (q << 4);
         int row = (int)__umulhi((uint32_t)e0, magic);
         const int col = e0 - row * W;
@@ -668,7 +672,8 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
             if (dbg && !dbg2 && tid == 0) p.dbg[(size_t)blk * 4 + 2] = wall_clock64();
             const int nrows = nag * 3 * W;
             stream_obs_u8(reinterpret_cast<uint8_t*>(obs_out), base, n, W, p.w_magic, tid, NT, p.store_policy == 1,
-                          [&](int row) -> uint32_t { return row < nrows ? (uint32_t)rows16[row] : 0u; });
+                          [&](int row) -> uint32_t { return row < nrows ? (uint32_t)rows16[row] : 0u; }, wave,
+                          (MW && !(p.flags & 512u)) ? nw : 1);
             if (dbg && !dbg2 && tid == 0) {
                 __builtin_amdgcn_s_waitcnt(0);
                 p.dbg[(size_t)blk * 4 + 3] = wall_clock64();
@@ -695,11 +700,20 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
         const uint32_t spol = (uint32_t)p.store_policy;
         const uint32_t* rows32 = smem;
         // flat float offset e0 = head + 4q advances by 4*NT per iteration: keep (row, col) incrementally
-        int e0 = head + (tid << 2);
+        // Multi-wave workgroups: every wave streams its own CONTIGUOUS part of the slice, 1 KiB per store instruction,
+        // like the single-wave kernel.  Interleaving the waves (q = tid, q += NT) makes each wave hop by NT * 16 bytes:
+        // with 4 waves that is 4 KiB, with 8 waves 8 KiB -- every store of a wave then lands on the same memory channel
+        // (configs[2] forced onto 3 / 4 / 8 waves: 120 / 147 / 419 us per step, profiles/r2/wave_span_ab.txt).
+        // PGX_FLAGS bit 9 restores the interleaved order for A/B.
+        const bool span = MW && !(p.flags & 512u);
+        const int part = (nvec + nw - 1) / nw;
+        const int q0 = span ? wave * part + lane : tid, q1 = span ? min(nvec, (wave + 1) * part) : nvec;
+        const int qs = span ? 64 : NT;
+        int e0 = head + (q0 << 2);
         int row = (int)__umulhi((uint32_t)e0, magic);
         int col = e0 - row * W;
-        const int drow = (4 * NT) / W, dcol = 4 * NT - drow * W;
-        for (int q = tid; q < nvec; q += NT) {
+        const int drow = (4 * qs) / W, dcol = 4 * qs - drow * W;
+        for (int q = q0; q < q1; q += qs) {
             const uint32_t w0 = rows32[row >> 1], w1 = rows32[(row >> 1) + 1];
             const uint32_t pair = (uint32_t)((((uint64_t)w1 << 32) | w0) >> (16 * (row & 1)));  // row | row+1 << 16
             const uint32_t b = ((pair & 0xFFFFu) >> col) | ((pair >> 16) << (W - col));
@@ -762,7 +776,8 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
     if (p.obs_u8) {
         const int nrows = nag * 3 * W;
         stream_obs_u8(reinterpret_cast<uint8_t*>(obs_out), (size_t)env0 * A * 3 * W * W, nrows * W, W, p.w_magic, tid, NT,
-                      p.store_policy == 1, [&](int row) -> uint32_t { return row < nrows ? s_rows[row] : 0u; });
+                      p.store_policy == 1, [&](int row) -> uint32_t { return row < nrows ? s_rows[row] : 0u; }, wave,
+                      (MW && !(p.flags & 512u)) ? nw : 1);
         return;
     }
     {
@@ -786,7 +801,11 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
         if (dbg && !dbg2 && tid == 0) p.dbg[(size_t)blk * 4 + 2] = wall_clock64();
         typedef float f32x4 __attribute__((ext_vector_type(4)));
         f32x4* out4 = reinterpret_cast<f32x4*>(out + head);
-        for (int q = tid; q < nvec; q += NT) {
+        const bool span = MW && !(p.flags & 512u);  // as in the P16 stream: contiguous part per wave
+        const int part = (nvec + nw - 1) / nw;
+        const int q0 = span ? wave * part + lane : tid, q1 = span ? min(nvec, (wave + 1) * part) : nvec;
+        const int qs = span ? 64 : NT;
+        for (int q = q0; q < q1; q += qs) {
             const int e0 = head + (q << 2);
             const int row = (int)__umulhi((uint32_t)e0, magic);
             const int col = e0 - row * W;
@@ -974,7 +993,7 @@ static const void* step_fn_for(const StepGeometry& g) {
 // G, waves per block, envs per wave, P16 and the LDS footprint for one configuration.
 //   epw_override > 0 forces the number of environments per wave (A <= 32 only; clamped to 64/G).
 StepGeometry step_geometry(int batch, int A, int bmw, int W, bool allow_p16, int epw_override, int obs_elem_bytes,
-                           int waves_override) {
+                           int waves_override, bool for_rollout) {
     StepGeometry g{};
     g.multi_wave = A > 64;
     g.G = 64;
@@ -991,6 +1010,15 @@ StepGeometry step_geometry(int batch, int A, int bmw, int W, bool allow_p16, int
             helpers = 2;
             while (helpers < 4 && batch * helpers < 1024) helpers <<= 1;  // 8 waves measured slower than 1
         }
+        // Three waves per environment for LARGE launches of 64-agent-class environments (>= 64 KB of float32
+        // observations each): 3 x batch waves no longer fit the chip at once, so the launch runs in overlapping rounds
+        // -- later workgroups compute under earlier ones' streams and finish in finer grains -- while each workgroup
+        // still idles only two waves during its state phase.  In-process A/B, same buffers (profiles/r2/helpers_ab.txt):
+        // configs[2] 123.6 -> 118.8 us (2 waves 123.9, 4 waves 145), batch 4096: 84.8 -> 82.8, batch 2048: 49.0 -> 44.5;
+        // worse for batch 1024 (26.0 -> 27.8), for 32- and 16-agent environments, for uint8 observations and inside a
+        // rollout launch (whose waves drift apart anyway: 114.6 -> 118.9), which keep one wave.
+        if (helpers == 1 && !for_rollout && A > 32 && batch >= 2048 && obs_elem_bytes == 4 && env_stream >= 64 * 1024)
+            helpers = 3;
         if (waves_override == 1) helpers = 1;
         else if (waves_override > 1) helpers = waves_override > 16 ? 16 : waves_override;
         if (helpers > 1) {
@@ -1046,12 +1074,12 @@ StepGeometry step_geometry(int batch, int A, int bmw, int W, bool allow_p16, int
 static hipError_t raise_lds_limit(const void* fn, size_t lds_bytes);
 static const void* rollout_fn_for(const StepGeometry& g);
 
-hipError_t prepare_step(const StepGeometry& g) {
+hipError_t prepare_step(const StepGeometry& g, const StepGeometry& roll) {
     const void* fn = step_fn_for(g);
-    const void* rfn = rollout_fn_for(g);
+    const void* rfn = rollout_fn_for(roll);
     if (!fn || !rfn) return hipErrorInvalidValue;
     if (hipError_t e = raise_lds_limit(fn, g.lds_bytes)) return e;
-    return raise_lds_limit(rfn, g.lds_bytes);
+    return raise_lds_limit(rfn, roll.lds_bytes);
 }
 
 static hipError_t raise_lds_limit(const void* fn, size_t lds_bytes) {

@@ -180,7 +180,7 @@ def test_rotation_cycles(A):
 HELPER_GEOMS = [g for g in GEOMETRIES if g[0] in ("baseline_cfg1", "dense_small", "full_wave", "odd_agents", "one_agent", "wide_window")]
 
 
-@pytest.mark.parametrize("waves", [1, 2, 4, 8])
+@pytest.mark.parametrize("waves", [1, 2, 3, 4, 8])  # 3: what large launches of 64-agent environments use
 @pytest.mark.parametrize("geom", HELPER_GEOMS, ids=[g[0] for g in HELPER_GEOMS])
 def test_helper_waves(geom, waves, monkeypatch):
     """num_agents <= 64 on the multi-wave kernel (helper waves that only share the observation write; chosen

@@ -849,6 +849,8 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : PGX_ROLL_OCC) void rollout
     typedef const __attribute__((address_space(4))) char KC;
     typedef const __attribute__((address_space(4))) StepParams KP;
     typedef const __attribute__((address_space(4))) RolloutParams KR;
+    // kernarg layout: explicit arguments in order, each at its natural alignment (code object v5)
+    static_assert(alignof(StepParams) == 8 && alignof(RolloutParams) == 8, "kernarg layout of rollout_kernel");
     constexpr size_t rp_offset = (sizeof(StepParams) + alignof(RolloutParams) - 1) / alignof(RolloutParams) * alignof(RolloutParams);
     const int steps = rp0.steps, slots = rp0.obs_slots;
     int slot = 0;

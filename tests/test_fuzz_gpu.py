@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import assert_rollouts_equal, c_oracle_rollout, engine_rollout, random_actions
+from util import assert_rollouts_equal, c_oracle_rollout, engine_rollout, engine_rollout_launch, random_actions
 
 pytestmark = pytest.mark.gpu
 
@@ -69,6 +69,10 @@ def test_random_configurations(chunk):
         got = engine_rollout(o, a, t, actions, action_dtype=c["action_dtype"],
                              obs_dtype=torch.uint8 if c["u8"] else None, **kw)
         assert_rollouts_equal(ref, got, f"fuzz chunk {chunk}: {c}")
+        # ... and the same episode as ONE launch (pgx_rollout)
+        got = engine_rollout_launch(o, a, t, actions, action_dtype=c["action_dtype"],
+                                    obs_dtype=torch.uint8 if c["u8"] else None, **kw)
+        assert_rollouts_equal(ref, got, f"fuzz chunk {chunk} as one rollout launch: {c}")
         done += 1
 
 

@@ -172,6 +172,34 @@ def engine_rollout(obstacles, agents, targets, actions, *, obs_radius, collision
     return out
 
 
+def engine_rollout_launch(obstacles, agents, targets, actions, *, obs_radius, collision_system, on_target,
+                          max_episode_steps, auto_reset, seed=0, env_index_base=0, action_dtype="int64",
+                          device="cuda:0", obs_dtype=None, empty_outside=True, semantics=None):
+    """The same rollout as ONE pgx_rollout launch (VecPogema.rollout).  Per-step positions are not exported by a
+    rollout: the dict carries the per-step outputs plus the FINAL agents_xy / targets_xy / elapsed in the last slice."""
+    import torch
+    from pogema_amd import GridConfig, VecPogema
+    T, B, A = actions.shape
+    gc = GridConfig(map=obstacles[0].tolist(), num_agents=A, obs_radius=obs_radius, collision_system=collision_system,
+                    on_target=on_target, max_episode_steps=max_episode_steps, seed=seed, empty_outside=empty_outside)
+    extra = {} if obs_dtype is None else {"obs_dtype": obs_dtype}
+    if semantics is not None:
+        extra["semantics"] = semantics
+    env = VecPogema(gc, batch=B, device=device, auto_reset=auto_reset, env_index_base=env_index_base, **extra)
+    obs0 = env.reset_from_state(obstacles, agents, targets)
+    tdt = {"int8": torch.int8, "int32": torch.int32, "int64": torch.int64}[action_dtype]
+    res = env.rollout(torch.from_numpy(actions).to(device).to(tdt))
+    done = res["episode_done"].cpu().numpy()
+    out = {"obs0": obs0.cpu().numpy(), "obs": res["obs"].cpu().numpy().astype(np.float32),
+           "rewards": res["rewards"].cpu().numpy(), "terminated": res["terminated"].cpu().numpy(),
+           "truncated": res["truncated"].cpu().numpy(), "is_active": res["is_active"].cpu().numpy(), "episode_done": done,
+           "metrics": np.where(done[..., None], res["metrics"].cpu().numpy(), 0)}
+    st = env.get_state()
+    out["final"] = {k: st[k].cpu().numpy() for k in ("agents_xy", "targets_xy", "elapsed")}
+    env.close()
+    return out
+
+
 def assert_rollouts_equal(ref, got, what=""):
     """Bit-exact for every integer/bool/index field and for the 0.0/1.0 float planes; rewards within
     1e-6 (BASELINE.json north_star tolerance)."""
@@ -185,6 +213,9 @@ def assert_rollouts_equal(ref, got, what=""):
             raise AssertionError(f"{what}: {key} differs first at index {tuple(bad)}: "
                                  f"oracle={ref[key][tuple(bad)]} engine={got[key][tuple(bad)]}")
     np.testing.assert_allclose(got["rewards"], ref["rewards"], rtol=0, atol=1e-6, err_msg=f"{what}: rewards")
+    if "final" in got:  # a rollout launch exports the state only once, at its end
+        for key, val in got["final"].items():
+            assert np.array_equal(ref[key][-1], val), f"{what}: final {key} differs"
     for key in ("obs0", "obs"):
         if not np.array_equal(ref[key], got[key]):
             bad = np.argwhere(ref[key] != got[key])[0]

@@ -37,4 +37,9 @@ for flags, labels in ((4, ("start", "state phase done", "row masks done / stream
         print(f"  {lab:32s} min/p10/p50/p90/max = " + " / ".join(f"{v:7.2f}" for v in q))
     d = t[:, 3] - t[:, 0]
     print(f"  per-workgroup lifetime (col3-col0) p50/max = {np.percentile(d,50):.2f} / {d.max():.2f}")
+    if flags == 4:  # how many workgroups are alive (started, stores not yet acknowledged) over the launch
+        end = t[:, 3].max()
+        grid = np.linspace(0, end, 25)
+        alive = [(int(((t[:, 0] <= g) & (t[:, 3] > g)).sum())) for g in grid]
+        print("  alive workgroups at " + " ".join(f"{g:.0f}us:{a}" for g, a in zip(grid, alive)))
     env.close()

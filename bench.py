@@ -232,8 +232,11 @@ class EngineStep:
                     f"{pl['candidates']} candidates, {pl['spacer_gib']:.0f} GiB of temporary spacers; plain store stream "
                     f"into the slowest buffer: {pl['buffer_gbs']:.0f} GB/s); observation stream timed into them "
                     f"{pl.get('observe_us_zone')} us vs best of torch's own buffers {pl.get('observe_us_torch_best')} us -> "
-                    f"kept {pl.get('chosen')} at {pl.get('observe_us')} us")
-        return f"{self.nbuf} output buffer(s) as torch's allocator returned them (no zone placement)"
+                    f"kept {pl.get('chosen')} at {pl.get('observe_us')} us; workgroups per XCD tuned to {pl.get('xcd_shares')}: "
+                    f"observation pass {pl.get('observe_us_equal_shares')} -> {pl.get('observe_us_tuned_shares')} us")
+        tuned = (f"; workgroups per XCD tuned to {pl['xcd_shares']}: observation pass {pl.get('observe_us_equal_shares')} -> "
+                 f"{pl.get('observe_us_tuned_shares')} us") if pl.get("xcd_shares") else ""
+        return f"{self.nbuf} output buffer(s) as torch's allocator returned them (no zone placement){tuned}"
 
     def box_store_stream_gbs(self):
         """What a bare store stream sustains on THIS box where the buffers lie (the zone walk's probe: 2 x 384 MiB,

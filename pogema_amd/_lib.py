@@ -51,7 +51,7 @@ EXPORTED_SYMBOLS = (
     "pgx_reset_from_state", "pgx_reset_random", "pgx_regenerate", "pgx_regenerate_failures", "pgx_get_map", "pgx_step", "pgx_observe", "pgx_set_metrics_buffers", "pgx_get_state", "pgx_generate", "pgx_place_agents",
     "pgx_snapshot_bytes", "pgx_save_snapshot", "pgx_load_snapshot", "pgx_time_observe", "pgx_bad_action_count",
     "pgx_buffers_create", "pgx_buffers_ptr", "pgx_buffers_get_info", "pgx_buffers_destroy", "pgx_set_targets",
-    "pgx_np_streams", "pgx_np_streams_host", "pgx_np_generate", "pgx_np_generate_host", "pgx_rollout", "pgx_buffers_stride", "pgx_buffers_drop",
+    "pgx_np_streams", "pgx_np_streams_host", "pgx_np_generate", "pgx_np_generate_host", "pgx_rollout", "pgx_buffers_stride", "pgx_buffers_drop", "pgx_xcd_shares", "pgx_xcd_tune",
 )
 
 
@@ -136,6 +136,10 @@ def load() -> C.CDLL:
     lib.pgx_np_generate.restype = C.c_int
     lib.pgx_np_generate_host.argtypes = [vp, i32, i32, i32, i32, C.c_double, vp, vp, vp, vp, vp, vp]
     lib.pgx_np_generate_host.restype = C.c_int
+    lib.pgx_xcd_tune.argtypes = [vp, vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), vp]
+    lib.pgx_xcd_tune.restype = C.c_int
+    lib.pgx_xcd_shares.argtypes = [vp, vp]
+    lib.pgx_xcd_shares.restype = C.c_int
     lib.pgx_buffers_drop.argtypes = [vp, i32]
     lib.pgx_buffers_drop.restype = C.c_int
     lib.pgx_buffers_stride.argtypes = [vp]

@@ -107,6 +107,7 @@ struct pgx_env {
     uint32_t* fail_count = nullptr;       // [1]
     uint32_t* regen_fail = nullptr;       // [1] sticky failure counter of pgx_regenerate
     uint32_t* bad_count = nullptr;        // [1] out-of-range actions (bad_action = FLAG)
+    float xcd_w[8] = {0.125f, 0.125f, 0.125f, 0.125f, 0.125f, 0.125f, 0.125f, 0.125f};  // shares of a launch per XCD
     uint32_t *labels = nullptr, *pending = nullptr;  // [chunk_envs][H*W], allocated on first use
     uint8_t* scratch_map = nullptr;       // [chunk_envs][H*W] draft maps
     int chunk_envs = 0;
@@ -118,6 +119,15 @@ extern "C" {
 int pgx_abi_version(void) { return PGX_ABI_VERSION; }
 
 const char* pgx_last_error(void) { return g_err.c_str(); }
+
+// (re)computes both launch shapes' per-XCD shares from e->xcd_w
+static void apply_xcd_shares(pgx_env* e) {
+    for (pgx::StepGeometry* g : {&e->geo, &e->geo_roll}) {
+        const int blocks = g->multi_wave ? e->cfg.batch : (e->cfg.batch + g->epw - 1) / g->epw;
+        g->grid = pgx::xcd_partition(blocks, e->xcd_w, g->xcd_n, g->xcd_base);
+        if (e->flags & 8u) g->grid = blocks;  // identity mapping (A/B)
+    }
+}
 
 int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
     if (!cfg || !out) return fail(PGX_E_INVALID, "pgx_create: null argument");
@@ -233,6 +243,15 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
         err = pgx::launch_init_np_lifelong(e->np_state0, cfg->seed, cfg->env_index_base, cfg->batch, A, nullptr);
     if (err == hipSuccess && e->np_state0) err = hipStreamSynchronize(nullptr);
     if (err == hipSuccess) err = pgx::prepare_step(e->geo, e->geo_roll);
+    if (const char* spec = getenv("PGX_XCD_WEIGHTS")) {  // eight comma-separated weights (diagnostic)
+        float f[8], sum = 0.f;
+        if (sscanf(spec, "%f,%f,%f,%f,%f,%f,%f,%f", &f[0], &f[1], &f[2], &f[3], &f[4], &f[5], &f[6], &f[7]) == 8) {
+            for (float q : f) sum += q > 0.f ? q : 0.f;
+            if (sum > 0.f)
+                for (int x = 0; x < 8; ++x) e->xcd_w[x] = (f[x] > 0.f ? f[x] : 0.f) / sum;
+        }
+    }
+    apply_xcd_shares(e);
     if (err != hipSuccess) {
         const char* msg = hipGetErrorString(err);
         const size_t need = e->geo.lds_bytes;
@@ -272,6 +291,7 @@ int64_t pgx_agent_elems(const pgx_env* e) {
 }
 
 static void fill_params(const pgx_env* e, pgx::StepParams& p);
+
 
 // ---- reset path ---------------------------------------------------------------------------------------
 // Scratch of the reset kernel: 9 bytes per cell and slot (draft map, labels, pending).  The synchronous resets
@@ -581,6 +601,10 @@ static void fill_params(const pgx_env* e, pgx::StepParams& p) {
     p.epw = e->geo.epw;
     p.stagger = e->geo.stagger;
     p.store_policy = e->geo.store_policy;
+    for (int x = 0; x < 8; ++x) {
+        p.xcd_n[x] = e->geo.xcd_n[x];
+        p.xcd_base[x] = e->geo.xcd_base[x];
+    }
     p.obs_u8 = e->cfg.obs_dtype == PGX_OBS_U8 ? 1 : 0;
     p.soft_rule = c.soft_vertex_rule;
     p.coop_reward = c.coop_reward;
@@ -673,6 +697,10 @@ int pgx_rollout(pgx_env* e, int32_t steps, const pgx_rollout_io* io, void* strea
     p.epw = e->geo_roll.epw;
     p.stagger = e->geo_roll.stagger;
     p.store_policy = e->geo_roll.store_policy;
+    for (int x = 0; x < 8; ++x) {
+        p.xcd_n[x] = e->geo_roll.xcd_n[x];
+        p.xcd_base[x] = e->geo_roll.xcd_base[x];
+    }
     PGX_HIP(pgx::launch_rollout(p, rp, e->geo_roll, (hipStream_t)stream));
     return PGX_OK;
 }
@@ -746,6 +774,89 @@ int pgx_time_observe(pgx_env* e, void* obs, int32_t reps, float* microseconds, v
     return PGX_OK;
 }
 
+int pgx_xcd_tune(pgx_env* e, void* obs, int32_t rounds, float* us_equal, float* us_tuned, void* stream) {
+    if (!e || !obs) return fail(PGX_E_INVALID, "pgx_xcd_tune: null argument");
+    if (!e->has_state) return fail(PGX_E_STATE, "pgx_xcd_tune called before a reset");
+    if (rounds < 1) rounds = 6;
+    DeviceGuard guard(e->device);
+    if (guard.err != hipSuccess) return fail(PGX_E_HIP, "cannot select device: %s", hipGetErrorString(guard.err));
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = e->geo.multi_wave ? e->cfg.batch : (e->cfg.batch + e->geo.epw - 1) / e->geo.epw;
+    const size_t nst = (size_t)blocks * 4;
+    unsigned long long* stamps = nullptr;
+    PGX_HIP(hipMalloc((void**)&stamps, nst * sizeof(unsigned long long)));
+    std::vector<unsigned long long> host(nst);
+    hipEvent_t a = nullptr, b = nullptr;
+    hipError_t err = hipEventCreate(&a);
+    if (err == hipSuccess) err = hipEventCreate(&b);
+    float best_w[8], w[8], best_us = 0.f, first_us = 0.f;
+    for (int x = 0; x < 8; ++x) best_w[x] = w[x] = 0.125f;
+    for (int round = 0; round <= rounds && err == hipSuccess; ++round) {
+        for (int x = 0; x < 8; ++x) e->xcd_w[x] = w[x];
+        apply_xcd_shares(e);
+        pgx::StepParams p;
+        fill_params(e, p);
+        p.mode = pgx::MODE_OBSERVE;
+        p.obs = static_cast<float*>(obs);
+        // how long the launch takes with these shares ...
+        err = pgx::launch_step(p, e->geo, s);
+        if (err == hipSuccess) err = hipEventRecord(a, s);
+        for (int i = 0; i < 4 && err == hipSuccess; ++i) err = pgx::launch_step(p, e->geo, s);
+        if (err == hipSuccess) err = hipEventRecord(b, s);
+        if (err == hipSuccess) err = hipEventSynchronize(b);
+        float ms = 0.f;
+        if (err == hipSuccess) err = hipEventElapsedTime(&ms, a, b);
+        const float us = ms * 250.0f;
+        if (round == 0) first_us = us;
+        if (round == 0 || us < best_us) {
+            best_us = us;
+            for (int x = 0; x < 8; ++x) best_w[x] = w[x];
+        }
+        if (round == rounds || err != hipSuccess) break;
+        // ... and when each XCD is through with its share (per-workgroup end stamps of one more launch)
+        err = hipMemsetAsync(stamps, 0, nst * sizeof(unsigned long long), s);
+        p.flags = (p.flags | 4u) & ~64u;
+        p.dbg = stamps;
+        if (err == hipSuccess) err = pgx::launch_step(p, e->geo, s);
+        if (err == hipSuccess) err = hipMemcpyAsync(host.data(), stamps, nst * sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
+        if (err == hipSuccess) err = hipStreamSynchronize(s);
+        if (err != hipSuccess) break;
+        unsigned long long t0 = ~0ull;
+        for (int i = 0; i < blocks; ++i)
+            if (host[(size_t)i * 4] && host[(size_t)i * 4] < t0) t0 = host[(size_t)i * 4];
+        double f[8], mean = 0.0;
+        for (int x = 0; x < 8; ++x) {
+            unsigned long long last = t0;
+            for (int i = e->geo.xcd_base[x]; i < e->geo.xcd_base[x] + e->geo.xcd_n[x]; ++i)
+                if (host[(size_t)i * 4 + 3] > last) last = host[(size_t)i * 4 + 3];
+            f[x] = (double)(last - t0);
+            mean += f[x] / 8.0;
+        }
+        if (getenv("PGX_DEBUG"))
+            fprintf(stderr, "[pgx xcd] round %d: %.1f us; shares %d %d %d %d %d %d %d %d finished after %.0f %.0f %.0f %.0f %.0f %.0f %.0f %.0f us\n",
+                    round, us, e->geo.xcd_n[0], e->geo.xcd_n[1], e->geo.xcd_n[2], e->geo.xcd_n[3], e->geo.xcd_n[4], e->geo.xcd_n[5],
+                    e->geo.xcd_n[6], e->geo.xcd_n[7], f[0] / 100, f[1] / 100, f[2] / 100, f[3] / 100, f[4] / 100, f[5] / 100,
+                    f[6] / 100, f[7] / 100);
+        // half of the correction the finish times ask for (an XCD that got less work also finishes the rest faster)
+        double sum = 0.0;
+        for (int x = 0; x < 8; ++x) {
+            const double v = f[x] > 0.0 ? (double)w[x] * (0.5 + 0.5 * mean / f[x]) : (double)w[x];
+            w[x] = (float)(v < 0.10 ? 0.10 : v > 0.15 ? 0.15 : v);
+            sum += w[x];
+        }
+        for (int x = 0; x < 8; ++x) w[x] = (float)(w[x] / sum);
+    }
+    for (int x = 0; x < 8; ++x) e->xcd_w[x] = best_w[x];
+    apply_xcd_shares(e);
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+    (void)hipFree(stamps);
+    PGX_HIP(err);
+    if (us_equal) *us_equal = first_us;
+    if (us_tuned) *us_tuned = best_us;
+    return PGX_OK;
+}
+
 int pgx_get_state(pgx_env* e, int32_t* agent_xy, int32_t* target_xy, uint8_t* is_active, int32_t* elapsed,
                   uint8_t* occupancy, void* stream) {
     if (!e) return fail(PGX_E_INVALID, "pgx_get_state: null handle");
@@ -767,6 +878,12 @@ int pgx_get_state(pgx_env* e, int32_t* agent_xy, int32_t* target_xy, uint8_t* is
 
 // Diagnostic only (not part of include/pogema_amd.h): copies the per-workgroup clock stamps of the last
 // launch to the host; needs PGX_FLAGS bit 2 at pgx_create.  Synchronises the device.
+int pgx_xcd_shares(pgx_env* e, int32_t* shares) {
+    if (!e || !shares) return fail(PGX_E_INVALID, "pgx_xcd_shares: null argument");
+    for (int x = 0; x < 8; ++x) shares[x] = e->geo.xcd_n[x];
+    return PGX_OK;
+}
+
 int pgx_debug_timestamps(pgx_env* e, unsigned long long* host_out, int64_t max_elems) {
     if (!e || !host_out) return fail(PGX_E_INVALID, "pgx_debug_timestamps: null argument");
     if (!e->dbg) return fail(PGX_E_STATE, "diagnostic stamps not enabled (PGX_FLAGS bit 2)");

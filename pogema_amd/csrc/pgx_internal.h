@@ -70,6 +70,8 @@ struct StepParams {
     int32_t soft_rule;    // PGX_SOFT_*  (docs/SPEC.md Q1)
     int32_t coop_reward;  // PGX_COOP_REWARD_* (Q4)
     int32_t bad_action;   // PGX_BAD_ACTION_* (Q7)
+    int32_t xcd_n[8];     // workgroups (= environment slices) given to each XCD, proportional to its measured store rate
+    int32_t xcd_base[8];  // first slice of each XCD (prefix sums of xcd_n): the slices of one XCD stay contiguous
     uint32_t flags;    // diagnostic switches (PGX_FLAGS env var at pgx_create): bit1 generic row path, bit2 time stamps, bit3 identity block mapping
     uint64_t seed;
     int64_t env_index_base;
@@ -127,11 +129,16 @@ struct StepGeometry {
     int stagger;      // > 0: odd wave slots sleep this many x 8128 cycles after issuing their loads
     int store_policy; // observation store flavour (pgx_kernels.hip: store_obs16)
     size_t lds_bytes;
+    // shares of the launch's workgroups per XCD (xcd_partition; equal until pgx_tune_xcd_shares or PGX_XCD_WEIGHTS)
+    int grid;             // workgroups to launch: 8 * the largest share
+    int32_t xcd_n[8], xcd_base[8];
 };
 StepGeometry step_geometry(int batch, int A, int bmw, int W, bool allow_p16, int epw_override, int obs_elem_bytes,
                            int waves_override, bool for_rollout = false);
 hipError_t prepare_step(const StepGeometry& g, const StepGeometry& roll);
 hipError_t launch_step(const StepParams& p, const StepGeometry& g, hipStream_t stream);
+// splits `blocks` workgroups over the XCDs by `w`; returns the grid size (8 * the largest share)
+int xcd_partition(int blocks, const float w[8], int32_t n[8], int32_t base[8]);
 hipError_t launch_rollout(const StepParams& p, const RolloutParams& rp, const StepGeometry& g, hipStream_t stream);
 
 // `only` (device u8 [batch], may be null): pack just the flagged environments

@@ -20,8 +20,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <array>
 #include <map>
 #include <mutex>
+#include <string>
+#include <vector>
 #include <utility>
 
 #include "pgx_internal.h"
@@ -279,10 +282,17 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
     // contiguous in memory, so each XCD's L2 writes back one contiguous eighth of the observation tensor: -11.5 % per
     // configs[4] step (523 -> 465 us), -2 % on configs[2], neutral on short launches (buffer-controlled A/B,
     // profiles/r1/controlled_ab.txt).  PGX_FLAGS bit 3 switches back to the identity mapping for A/B.
+    // The XCDs do not get through their streams equally fast (the odd ones lag 5-15 %, whatever they write to:
+    // profiles/r2/xcd_rates.txt), so the shares need not be equal (pgx_tune_xcd_shares): workgroup b is the (b >> 3)-th
+    // of XCD b & 7 and takes slice xcd_base + (b >> 3) if that XCD still has one.
     int blk = blockIdx.x;
     if (!(p.flags & 8u)) {
-        const int per_xcd = gridDim.x >> 3;
-        if (blk < (per_xcd << 3)) blk = (blk & 7) * per_xcd + (blk >> 3);
+        // PGX_FLAGS bits 10..12 (diagnostic): XCD x takes the share of XCD (x + rot) & 7 -- does a slow XCD stay slow?
+        const int x = ((blk & 7) + (int)((p.flags >> 10) & 7u)) & 7, k = blk >> 3;
+        if (k >= p.xcd_n[x]) return;
+        blk = p.xcd_base[x] + k;
+    } else if (blk >= (MW ? p.batch : (p.batch + epw - 1) / epw)) {
+        return;
     }
     const int env0 = blk * epw;
     const int nenv = min(epw, p.batch - env0);
@@ -1115,21 +1125,37 @@ static const void* rollout_fn_for(const StepGeometry& g) {
 hipError_t launch_rollout(const StepParams& p, const RolloutParams& rp, const StepGeometry& g, hipStream_t stream) {
     const void* fn = rollout_fn_for(g);
     if (!fn) return hipErrorInvalidValue;
-    const int blocks = g.multi_wave ? p.batch : (p.batch + g.epw - 1) / g.epw;
     StepParams args = p;
     RolloutParams rargs = rp;
     void* kargs[] = {&args, &rargs};
-    return hipLaunchKernel(fn, dim3(blocks), dim3(64 * g.waves), kargs, g.lds_bytes, stream);
+    return hipLaunchKernel(fn, dim3(g.grid), dim3(64 * g.waves), kargs, g.lds_bytes, stream);
+}
+
+// ---- shares of a launch's workgroups per XCD -------------------------------------------------------------------------
+int xcd_partition(int blocks, const float w[8], int32_t n[8], int32_t base[8]) {
+    double acc = 0.0;
+    int given = 0, grid = 0;
+    for (int x = 0; x < 8; ++x) {  // cumulative rounding: the shares add up to `blocks` exactly
+        acc += (double)w[x];
+        int upto = x == 7 ? blocks : (int)(acc * blocks + 0.5);
+        if (upto > blocks) upto = blocks;
+        if (upto < given) upto = given;
+        n[x] = upto - given;
+        base[x] = given;
+        given = upto;
+        if (n[x] > grid) grid = n[x];
+    }
+    return grid * 8;
 }
 
 hipError_t launch_step(const StepParams& p, const StepGeometry& g, hipStream_t stream) {
     const void* fn = step_fn_for(g);
     if (!fn) return hipErrorInvalidValue;
-    const int blocks = g.multi_wave ? p.batch : (p.batch + g.epw - 1) / g.epw;
     StepParams args = p;
     void* kargs[] = {&args};
-    return hipLaunchKernel(fn, dim3(blocks), dim3(64 * g.waves), kargs, g.lds_bytes, stream);
+    return hipLaunchKernel(fn, dim3(g.grid), dim3(64 * g.waves), kargs, g.lds_bytes, stream);
 }
+
 
 hipError_t launch_pack_obstacles(const uint8_t* obstacles, const uint8_t* only, uint32_t* bm, int batch, int H, int Wd,
                                  int r, int wpr, int bmw, const OutsideParams& outside, hipStream_t stream) {

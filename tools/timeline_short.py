@@ -42,4 +42,12 @@ for flags, labels in ((4, ("start", "state phase done", "row masks done / stream
         grid = np.linspace(0, end, 25)
         alive = [(int(((t[:, 0] <= g) & (t[:, 3] > g)).sum())) for g in grid]
         print("  alive workgroups at " + " ".join(f"{g:.0f}us:{a}" for g, a in zip(grid, alive)))
+        shares = (C.c_int32 * 8)()
+        _lib.check(lib.pgx_xcd_shares(env._handle, shares))
+        base = np.concatenate([[0], np.cumsum(list(shares))])
+        rot = (base_flags >> 10) & 7
+        sl = [((x + rot) & 7) for x in range(8)]  # share written by XCD x
+        print(f"  per XCD (rot {rot}; shares {list(shares)}): last stores acknowledged at " +
+              " ".join(f"{t[base[s]:base[s + 1], 3].max():.0f}" for s in sl) + " | median " +
+              " ".join(f"{np.median(t[base[s]:base[s + 1], 3]):.0f}" for s in sl))
     env.close()

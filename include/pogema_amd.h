@@ -195,13 +195,13 @@ int pgx_step(pgx_env* env, const void* actions, int action_dtype, void* obs, flo
 /* How pgx_step's workgroups (one per environment, or per group of small environments) are shared out over the 8 XCDs:
  * shares[x] of them run on XCD x (host pointer, 8 entries).  Equal by default.  The XCDs do not get through their
  * observation streams equally fast (the odd ones lag 5-15 %), and with equal shares the fast ones
- * idle at the end of every launch: pgx_xcd_tune() runs the observation pass into `obs` (the buffer pgx_step will write)
- * a few times, reads when each XCD finished its share, shifts work towards the fast ones and keeps the shares that gave
+ * idle at the end of every launch: pgx_xcd_tune() runs the observation pass into `obs` and `obs_alt` in turn (the buffers
+ * pgx_step will write; obs_alt may be NULL) a few times, reads when each XCD finished its share, shifts work towards the fast ones and keeps the shares that gave
  * the shortest launch (never worse than equal: equal is the first candidate).  Synchronises `stream`; nothing in the
  * engine's state changes.  us_equal / us_tuned (may be NULL): the pass with equal shares and with the kept ones.
  * PGX_XCD_WEIGHTS=w0,...,w7 sets the shares at pgx_create instead (diagnostic). */
 int pgx_xcd_shares(pgx_env* env, int32_t* shares);
-int pgx_xcd_tune(pgx_env* env, void* obs, int32_t rounds, float* us_equal, float* us_tuned, void* stream);
+int pgx_xcd_tune(pgx_env* env, void* obs, void* obs_alt, int32_t rounds, float* us_equal, float* us_tuned, void* stream);
 
 /* K steps in ONE launch: the same as `steps` consecutive pgx_step calls with actions[t] -- bit for bit, state and outputs
  * -- for callers that have the actions up front (executing MAPF plans, scripted or random policies, replaying recorded

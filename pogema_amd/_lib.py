@@ -136,7 +136,7 @@ def load() -> C.CDLL:
     lib.pgx_np_generate.restype = C.c_int
     lib.pgx_np_generate_host.argtypes = [vp, i32, i32, i32, i32, C.c_double, vp, vp, vp, vp, vp, vp]
     lib.pgx_np_generate_host.restype = C.c_int
-    lib.pgx_xcd_tune.argtypes = [vp, vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), vp]
+    lib.pgx_xcd_tune.argtypes = [vp, vp, vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), vp]
     lib.pgx_xcd_tune.restype = C.c_int
     lib.pgx_xcd_shares.argtypes = [vp, vp]
     lib.pgx_xcd_shares.restype = C.c_int

@@ -774,7 +774,7 @@ int pgx_time_observe(pgx_env* e, void* obs, int32_t reps, float* microseconds, v
     return PGX_OK;
 }
 
-int pgx_xcd_tune(pgx_env* e, void* obs, int32_t rounds, float* us_equal, float* us_tuned, void* stream) {
+int pgx_xcd_tune(pgx_env* e, void* obs, void* obs_alt, int32_t rounds, float* us_equal, float* us_tuned, void* stream) {
     if (!e || !obs) return fail(PGX_E_INVALID, "pgx_xcd_tune: null argument");
     if (!e->has_state) return fail(PGX_E_STATE, "pgx_xcd_tune called before a reset");
     if (rounds < 1) rounds = 6;
@@ -798,22 +798,8 @@ int pgx_xcd_tune(pgx_env* e, void* obs, int32_t rounds, float* us_equal, float* 
         fill_params(e, p);
         p.mode = pgx::MODE_OBSERVE;
         p.obs = static_cast<float*>(obs);
-        // how long the launch takes with these shares ...
-        err = pgx::launch_step(p, e->geo, s);
-        if (err == hipSuccess) err = hipEventRecord(a, s);
-        for (int i = 0; i < 4 && err == hipSuccess; ++i) err = pgx::launch_step(p, e->geo, s);
-        if (err == hipSuccess) err = hipEventRecord(b, s);
-        if (err == hipSuccess) err = hipEventSynchronize(b);
-        float ms = 0.f;
-        if (err == hipSuccess) err = hipEventElapsedTime(&ms, a, b);
-        const float us = ms * 250.0f;
-        if (round == 0) first_us = us;
-        if (round == 0 || us < best_us) {
-            best_us = us;
-            for (int x = 0; x < 8; ++x) best_w[x] = w[x];
-        }
-        if (round == rounds || err != hipSuccess) break;
-        // ... and when each XCD is through with its share (per-workgroup end stamps of one more launch)
+        float* const two[2] = {static_cast<float*>(obs), static_cast<float*>(obs_alt ? obs_alt : obs)};
+        // when each XCD is through with its share (per-workgroup end stamps of one launch) ...
         err = hipMemsetAsync(stamps, 0, nst * sizeof(unsigned long long), s);
         p.flags = (p.flags | 4u) & ~64u;
         p.dbg = stamps;
@@ -832,11 +818,36 @@ int pgx_xcd_tune(pgx_env* e, void* obs, int32_t rounds, float* us_equal, float* 
             f[x] = (double)(last - t0);
             mean += f[x] / 8.0;
         }
+        // ... and how long the launch takes with these shares: alternating between the two buffers as pgx_step's caller
+        // does, always after the same prelude (the stamped launch and its read-back), two passes to settle, four timed
+        p.flags = e->flags;
+        p.dbg = e->dbg;
+        for (int i = 0; i < 2 && err == hipSuccess; ++i) {
+            p.obs = two[i & 1];
+            err = pgx::launch_step(p, e->geo, s);
+        }
+        if (err == hipSuccess) err = hipEventRecord(a, s);
+        for (int i = 0; i < 4 && err == hipSuccess; ++i) {
+            p.obs = two[i & 1];
+            err = pgx::launch_step(p, e->geo, s);
+        }
+        if (err == hipSuccess) err = hipEventRecord(b, s);
+        if (err == hipSuccess) err = hipEventSynchronize(b);
+        float ms = 0.f;
+        if (err == hipSuccess) err = hipEventElapsedTime(&ms, a, b);
+        if (err != hipSuccess) break;
+        const float us = ms * 250.0f;
+        if (round == 0) first_us = us;
+        if (round == 0 || us < best_us) {
+            best_us = us;
+            for (int x = 0; x < 8; ++x) best_w[x] = w[x];
+        }
         if (getenv("PGX_DEBUG"))
             fprintf(stderr, "[pgx xcd] round %d: %.1f us; shares %d %d %d %d %d %d %d %d finished after %.0f %.0f %.0f %.0f %.0f %.0f %.0f %.0f us\n",
                     round, us, e->geo.xcd_n[0], e->geo.xcd_n[1], e->geo.xcd_n[2], e->geo.xcd_n[3], e->geo.xcd_n[4], e->geo.xcd_n[5],
                     e->geo.xcd_n[6], e->geo.xcd_n[7], f[0] / 100, f[1] / 100, f[2] / 100, f[3] / 100, f[4] / 100, f[5] / 100,
                     f[6] / 100, f[7] / 100);
+        if (round == rounds) break;
         // half of the correction the finish times ask for (an XCD that got less work also finishes the rest faster)
         double sum = 0.0;
         for (int x = 0; x < 8; ++x) {

@@ -375,7 +375,7 @@ class VecPogema:
             self.placement = {"spread": False, "method": "torch allocator"}
             bufs = [torch.empty(self.obs_shape, dtype=self.obs_dtype, device=self.device) for _ in range(n)]
             if self.placement_probe and self.batch >= 2048:
-                self.placement.update(self.tune_xcd_shares(bufs[0]))
+                self.placement.update(self.tune_xcd_shares(bufs[0], bufs[-1] if n > 1 else None))
             return bufs
         from .buffers import ZoneBuffers
         # The walk's verdict does not always carry over to the real buffers (halves may straddle a boundary), and some
@@ -405,7 +405,7 @@ class VecPogema:
                               observe_us_torch_best=round(min((c[0] for c in other), default=0.0), 1))
         kept = {c[1] for c in chosen if c[2] == "zone"}
         result = [c[3] for c in chosen]
-        self.placement.update(self.tune_xcd_shares(result[0]))
+        self.placement.update(self.tune_xcd_shares(result[0], result[-1] if n > 1 else None))
         del cands, other, zone, chosen
         for i in range(n + spare):
             if i not in kept:
@@ -413,13 +413,14 @@ class VecPogema:
         torch.cuda.empty_cache()
         return result
 
-    def tune_xcd_shares(self, obs: torch.Tensor, rounds: int = 6) -> dict:
+    def tune_xcd_shares(self, obs: torch.Tensor, obs_alt: Optional[torch.Tensor] = None, rounds: int = 6) -> dict:
         """pgx_xcd_tune: shift work between the 8 XCDs until they finish a launch together (the odd XCDs get through
         their streams 5-15 % slower); keeps the shares with the shortest observation pass, equal shares included."""
         if not self._has_state():
             return {}
         eq, tuned = C.c_float(0.0), C.c_float(0.0)
-        _lib.check(self._lib.pgx_xcd_tune(self._handle, obs.data_ptr(), int(rounds), C.byref(eq), C.byref(tuned), self._stream()))
+        _lib.check(self._lib.pgx_xcd_tune(self._handle, obs.data_ptr(), obs_alt.data_ptr() if obs_alt is not None else None,
+                                          int(rounds), C.byref(eq), C.byref(tuned), self._stream()))
         shares = (C.c_int32 * 8)()
         _lib.check(self._lib.pgx_xcd_shares(self._handle, shares))
         return {"xcd_shares": list(shares), "observe_us_equal_shares": round(eq.value, 1), "observe_us_tuned_shares": round(tuned.value, 1)}
@@ -579,7 +580,7 @@ class VecPogema:
                                           observe_us=[round(t, 1) for t in times[start:start + slots]],
                                           observe_us_zone=[round(t, 1) for t in times])
                     if "xcd_shares" not in self.placement and self._bufs is None:
-                        self.placement.update(self.tune_xcd_shares(ring[0]))
+                        self.placement.update(self.tune_xcd_shares(ring[0], ring[1] if slots > 1 else None))
                 obs, slot_stride = entry[1], entry[0].stride_bytes
             else:
                 obs = torch.empty((slots,) + self.obs_shape, dtype=self.obs_dtype, device=dev)

@@ -390,3 +390,50 @@ def test_single_output_buffer_mode():
         VecPogema(gc, batch=2, reuse_buffers="double")
     a.close()
     b.close()
+
+
+def test_unequal_xcd_shares_change_nothing_but_the_schedule(monkeypatch):
+    """Workgroups per XCD (pgx_xcd_shares / pgx_xcd_tune / PGX_XCD_WEIGHTS): whatever the shares, every slice is
+    processed exactly once and the results are those of equal shares."""
+    import ctypes as C
+    import torch
+    from pogema_amd import GridConfig, VecPogema, _lib as L
+    from util import random_actions
+    B, A = 203, 8  # 203 workgroups: shares that do not divide
+    gc = GridConfig(size=16, num_agents=A, obs_radius=4, density=0.2, collision_system="soft", max_episode_steps=9, seed=3)
+    actions = torch.as_tensor(random_actions(12, B, A, seed=1), device="cuda:0")
+
+    def run(weights):
+        if weights is None:
+            monkeypatch.delenv("PGX_XCD_WEIGHTS", raising=False)
+        else:
+            monkeypatch.setenv("PGX_XCD_WEIGHTS", weights)
+        env = VecPogema(gc, batch=B, device="cuda:0", auto_reset=True)
+        obs0, _ = env.reset(seed=5)
+        shares = (C.c_int32 * 8)()
+        L.check(env._lib.pgx_xcd_shares(env._handle, shares))
+        outs = [obs0.clone()]
+        for t in range(12):
+            o, r, te, tr, _ = env.step(actions[t])
+            outs += [o.clone(), r.clone(), te.clone(), tr.clone()]
+        roll = env.rollout(actions[:5])
+        outs += [roll["obs"], roll["rewards"]]
+        return list(shares), outs, env
+
+    s_eq, ref, _ = run(None)
+    assert sum(s_eq) == B and max(s_eq) - min(s_eq) <= 1
+    for spec in ("3,1,2,1,1,1,1,1", "1,0,0,0,0,0,0,0", "0,0,0,5,0,0,0,1"):
+        s, got, _ = run(spec)
+        assert sum(s) == B and s != s_eq
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b), spec
+    # the tuner keeps equal shares when nothing is faster, always returns a valid partition, and leaves the state alone
+    monkeypatch.delenv("PGX_XCD_WEIGHTS", raising=False)
+    env = VecPogema(gc, batch=B, device="cuda:0", auto_reset=True)
+    obs0, _ = env.reset(seed=5)
+    buf = torch.empty_like(obs0)
+    info = env.tune_xcd_shares(buf, rounds=3)
+    assert sum(info["xcd_shares"]) == B and info["observe_us_tuned_shares"] <= info["observe_us_equal_shares"]
+    assert torch.equal(buf, obs0)
+    o, *_ = env.step(actions[0])
+    assert torch.equal(o, ref[1])

@@ -244,6 +244,21 @@ void find_other_zone(int device, size_t budget, std::vector<Range>& held, pgx_bu
             return;
         }
     }
+    if (getenv("PGX_ZONE_PAIRS")) {  // diagnostic: nothing pairs with the reference -- do the candidates pair with each other?
+        std::vector<void*> c;
+        for (size_t i = 1; i < held.size(); ++i)
+            if (held[i].bytes == PROBE_HALF) c.push_back(held[i].va);  // held[1] = baseline candidate, then one per spacer
+        fprintf(stderr, "[pgx_buffers] pair scan over %zu candidates (every 3rd), us:\n", c.size());
+        for (size_t i = 0; i < c.size(); i += 3) {
+            fprintf(stderr, "[pgx_buffers]   %3zu:", i);
+            for (size_t j = 0; j < c.size(); j += 3) {
+                float t = 0.f;
+                if (j <= i || probe_us(c[i], c[j], PROBE_HALF, &t) != hipSuccess) fprintf(stderr, "     .");
+                else fprintf(stderr, " %5.0f", t);
+            }
+            fprintf(stderr, "\n");
+        }
+    }
 }
 
 }  // namespace

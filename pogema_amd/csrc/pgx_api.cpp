@@ -819,7 +819,7 @@ int pgx_xcd_tune(pgx_env* e, void* obs, void* obs_alt, int32_t rounds, float* us
             mean += f[x] / 8.0;
         }
         // ... and how long the launch takes with these shares: alternating between the two buffers as pgx_step's caller
-        // does, always after the same prelude (the stamped launch and its read-back), two passes to settle, four timed
+        // does, always after the same prelude (the stamped launch and its read-back), two passes to settle, eight timed
         p.flags = e->flags;
         p.dbg = e->dbg;
         for (int i = 0; i < 2 && err == hipSuccess; ++i) {
@@ -827,7 +827,8 @@ int pgx_xcd_tune(pgx_env* e, void* obs, void* obs_alt, int32_t rounds, float* us
             err = pgx::launch_step(p, e->geo, s);
         }
         if (err == hipSuccess) err = hipEventRecord(a, s);
-        for (int i = 0; i < 4 && err == hipSuccess; ++i) {
+        const int timed = 8;
+        for (int i = 0; i < timed && err == hipSuccess; ++i) {
             p.obs = two[i & 1];
             err = pgx::launch_step(p, e->geo, s);
         }
@@ -836,7 +837,7 @@ int pgx_xcd_tune(pgx_env* e, void* obs, void* obs_alt, int32_t rounds, float* us
         float ms = 0.f;
         if (err == hipSuccess) err = hipEventElapsedTime(&ms, a, b);
         if (err != hipSuccess) break;
-        const float us = ms * 250.0f;
+        const float us = ms * 1000.0f / (float)timed;
         if (round == 0) first_us = us;
         if (round == 0 || us < best_us) {
             best_us = us;

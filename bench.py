@@ -227,7 +227,7 @@ class EngineStep:
     def describe_buffers(self):
         pl = getattr(self.env, "placement", None) or {}
         if pl.get("method", "").startswith("pgx_buffers"):
-            return (f"{self.nbuf} alternating buffers from the engine's zone-aware pool: halves in two HBM zones = {pl['spread']} "
+            return (f"{self.nbuf} alternating buffers from the engine's zone-aware pool ({pl.get('pools_tried', 1)} tried): halves in two HBM zones = {pl['spread']} "
                     f"(probe stream {pl['same_zone_us']:.1f} us same-zone -> {pl['final_us']:.1f} us as placed, "
                     f"{pl['candidates']} candidates, {pl['spacer_gib']:.0f} GiB of temporary spacers; plain store stream "
                     f"into the slowest buffer: {pl['buffer_gbs']:.0f} GB/s); observation stream timed into them "

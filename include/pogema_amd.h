@@ -307,6 +307,10 @@ typedef struct pgx_buffers_info {
     float reserved1;
 } pgx_buffers_info;
 int pgx_buffers_create(int device, size_t bytes, int count, double max_spacer_gib, pgx_buffers** out);
+/* The same, with the first `skip_gib` of the walk passed over unprobed: for a caller whose own stream turned out slower
+ * into the buffers of a first pool than its probe promised (the fast stretch was narrower than the buffers) and who
+ * tries again further on (`info.spacer_gib` of the first pool + 16, say). */
+int pgx_buffers_create_at(int device, size_t bytes, int count, double skip_gib, double max_spacer_gib, pgx_buffers** out);
 void* pgx_buffers_ptr(pgx_buffers* pool, int index); /* device pointer of buffer `index`, NULL if out of range */
 int64_t pgx_buffers_stride(pgx_buffers* pool);       /* all buffers lie in ONE virtual range: ptr(i) = ptr(0) + i * stride,
                                                         stride = bytes rounded up to 2 MiB (pgx_rollout_io.obs_slot_stride) */

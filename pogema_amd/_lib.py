@@ -51,7 +51,7 @@ EXPORTED_SYMBOLS = (
     "pgx_reset_from_state", "pgx_reset_random", "pgx_regenerate", "pgx_regenerate_failures", "pgx_get_map", "pgx_step", "pgx_observe", "pgx_set_metrics_buffers", "pgx_get_state", "pgx_generate", "pgx_place_agents",
     "pgx_snapshot_bytes", "pgx_save_snapshot", "pgx_load_snapshot", "pgx_time_observe", "pgx_bad_action_count",
     "pgx_buffers_create", "pgx_buffers_ptr", "pgx_buffers_get_info", "pgx_buffers_destroy", "pgx_set_targets",
-    "pgx_np_streams", "pgx_np_streams_host", "pgx_np_generate", "pgx_np_generate_host", "pgx_rollout", "pgx_buffers_stride", "pgx_buffers_drop", "pgx_xcd_shares", "pgx_xcd_tune",
+    "pgx_np_streams", "pgx_np_streams_host", "pgx_np_generate", "pgx_np_generate_host", "pgx_rollout", "pgx_buffers_stride", "pgx_buffers_drop", "pgx_xcd_shares", "pgx_xcd_tune", "pgx_buffers_create_at",
 )
 
 
@@ -122,6 +122,8 @@ def load() -> C.CDLL:
     lib.pgx_get_map.argtypes = [vp, vp, vp]
     lib.pgx_buffers_create.argtypes = [C.c_int, C.c_size_t, C.c_int, C.c_double, C.POINTER(vp)]
     lib.pgx_buffers_create.restype = C.c_int
+    lib.pgx_buffers_create_at.argtypes = [C.c_int, C.c_size_t, C.c_int, C.c_double, C.c_double, C.POINTER(vp)]
+    lib.pgx_buffers_create_at.restype = C.c_int
     lib.pgx_buffers_ptr.argtypes = [vp, C.c_int]
     lib.pgx_buffers_ptr.restype = vp
     lib.pgx_buffers_get_info.argtypes = [vp, C.POINTER(PgxBuffersInfo)]

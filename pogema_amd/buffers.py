@@ -49,7 +49,7 @@ class ZoneBuffers:
     be 40 ... > 128 GiB away from where the allocator stands (profiles/r2/placement_walk_scan.txt), so the default lets
     the walk use all free memory: PGX_ZONE_SPACER_GIB or 272; 0 disables the search.  PGX_DEBUG=1 traces the walk."""
 
-    def __init__(self, shape, dtype, device, count=2, max_spacer_gib=None):
+    def __init__(self, shape, dtype, device, count=2, max_spacer_gib=None, skip_gib=0.0):
         if dtype not in _TYPESTR:
             raise ValueError(f"unsupported dtype {dtype}")
         dev = torch.device(device)
@@ -60,7 +60,7 @@ class ZoneBuffers:
         nbytes = int(np.prod(shape)) * (4 if dtype == torch.float32 else 1)
         handle = C.c_void_p()
         torch.cuda.synchronize(index)  # the search times kernels on the default stream
-        _lib.check(lib.pgx_buffers_create(index, nbytes, int(count), float(max_spacer_gib), C.byref(handle)))
+        _lib.check(lib.pgx_buffers_create_at(index, nbytes, int(count), float(skip_gib), float(max_spacer_gib), C.byref(handle)))
         self._owner = _Owner(lib, handle)
         info = _lib.PgxBuffersInfo()
         _lib.check(lib.pgx_buffers_get_info(handle, C.byref(info)))

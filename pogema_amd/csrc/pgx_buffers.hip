@@ -192,7 +192,7 @@ hipError_t make_chunk(int device, size_t bytes, Range& r) {
 // reference and half into the candidate.  Nothing is freed during the walk (a freed chunk would be handed out again
 // and the walk would stand still): `held` keeps spacers, reference and candidates until the caller has allocated the
 // second halves.  On return with *found the allocator sits right behind a candidate that lies in another zone.
-void find_other_zone(int device, size_t budget, std::vector<Range>& held, pgx_buffers_info& info, bool* found) {
+void find_other_zone(int device, size_t budget, size_t skip, std::vector<Range>& held, pgx_buffers_info& info, bool* found) {
     *found = false;
     held.emplace_back();
     if (make_chunk(device, PROBE_HALF, held.back()) != hipSuccess) { held.pop_back(); return; }
@@ -205,11 +205,18 @@ void find_other_zone(int device, size_t budget, std::vector<Range>& held, pgx_bu
     // A one-zone stream sustains 5.4-6.2 TB/s on the devices measured, a 1:1 two-zone stream 6.7-7.0 TB/s: a pair that
     // already reaches 6.6 TB/s straddles a zone boundary as it is -- the allocator stands in the other zone already.
     const float t_spread_abs = (float)(2.0 * (double)PROBE_HALF / 6.6e12 * 1e6);
-    if (t_same <= t_spread_abs) {
+    if (t_same <= t_spread_abs && skip == 0) {
         *found = true;
         return;
     }
     size_t spacer_bytes = 0;
+    // `skip`: a previous attempt ended this far into the walk and its buffers did not deliver -- pass over that stretch
+    while (spacer_bytes < skip && spacer_bytes + SPACER <= budget) {
+        held.emplace_back();
+        if (make_chunk(device, SPACER, held.back()) != hipSuccess) { held.pop_back(); (void)hipGetLastError(); return; }
+        spacer_bytes += SPACER;
+        info.spacer_gib = (double)spacer_bytes / (double)GiB;
+    }
     int weak_run = 0;
     bool prev_strong = false;
     while (spacer_bytes + SPACER <= budget) {
@@ -266,6 +273,10 @@ void find_other_zone(int device, size_t budget, std::vector<Range>& held, pgx_bu
 extern "C" {
 
 int pgx_buffers_create(int device, size_t bytes, int count, double max_spacer_gib, pgx_buffers** out) {
+    return pgx_buffers_create_at(device, bytes, count, 0.0, max_spacer_gib, out);
+}
+
+int pgx_buffers_create_at(int device, size_t bytes, int count, double skip_gib, double max_spacer_gib, pgx_buffers** out) {
     if (!out) return pgx::fail_msg(PGX_E_INVALID, "pgx_buffers_create: null argument");
     *out = nullptr;
     if (bytes == 0 || count < 1 || count > 64) return pgx::fail_msg(PGX_E_INVALID, "pgx_buffers_create: bad size or count");
@@ -313,7 +324,8 @@ int pgx_buffers_create(int device, size_t bytes, int count, double max_spacer_gi
         const size_t need = (size_t)count * p->second + 20 * PROBE_HALF + 4 * GiB;
         size_t budget = (size_t)(max_spacer_gib * (double)GiB);
         budget = std::min(budget, free_b > need ? (free_b - need) / 10 * 9 : 0);
-        find_other_zone(device, budget, held, p->info, &found);
+        const size_t skip = skip_gib > 0.0 ? (size_t)(skip_gib * (double)GiB) : 0;
+        find_other_zone(device, budget, skip, held, p->info, &found);
         (void)hipGetLastError();
     }
     // 3. second halves, right behind the last candidate of the walk (everything the walk allocated is still held)

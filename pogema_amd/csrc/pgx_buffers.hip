@@ -98,7 +98,7 @@ hipError_t grant_access(int device, void* va, size_t bytes) {
 
 void drop_part(Part& part) {
     if (!part.live) return;
-    (void)hipMemUnmap(part.va, part.bytes);
+    if (part.va) (void)hipMemUnmap(part.va, part.bytes);
     (void)hipMemRelease(part.handle);
     part.live = false;
 }
@@ -120,7 +120,8 @@ struct Range {
         // The address range itself is NOT given back (hipMemAddressFree): on ROCm 7.2 a range that is freed, reserved
         // again at the same address and mapped to new memory can keep answering with its OLD translation -- stores that
         // never arrive, then "Memory access fault by GPU" (tools/vmm_ring_repro.py: 2 of 2 runs within 6 pools; 0 of 36
-        // pools with the ranges kept).  Only address space leaks, <= ~0.3 TiB per zone walk out of 128 TiB.
+        // pools with the ranges kept).  Only address space leaks: the buffers' own ranges and ~13 GiB of probe chunks
+        // per zone walk out of 128 TiB (the spacers are never mapped).
         // PGX_VA_FREE=1 restores the free (diagnostic).
         if (va && getenv("PGX_VA_FREE")) (void)hipMemAddressFree(va, bytes);
         va = nullptr;
@@ -187,6 +188,22 @@ hipError_t make_chunk(int device, size_t bytes, Range& r) {
     return e;
 }
 
+// physical memory only, mapped nowhere: a spacer is never read or written, it just keeps the allocator from handing the
+// same pages out again (hipMemCreate commits the memory at once) -- and takes no address space
+hipError_t make_spacer(int device, size_t bytes, Range& r) {
+    r.parts.resize(1);
+    const hipMemAllocationProp prop = device_prop(device);
+    const hipError_t e = hipMemCreate(&r.parts[0].handle, bytes, &prop, 0);
+    if (e != hipSuccess) {
+        r.parts.clear();
+        return e;
+    }
+    r.parts[0].bytes = bytes;
+    r.parts[0].live = true;
+    r.bytes = bytes;
+    return hipSuccess;
+}
+
 // Walks the allocator into another zone.  A reference chunk is allocated first (right behind the buffers' first
 // halves: their zone); then, after every spacer, a candidate chunk; the probe stream writes half of its bytes into the
 // reference and half into the candidate.  Nothing is freed during the walk (a freed chunk would be handed out again
@@ -213,7 +230,7 @@ void find_other_zone(int device, size_t budget, size_t skip, std::vector<Range>&
     // `skip`: a previous attempt ended this far into the walk and its buffers did not deliver -- pass over that stretch
     while (spacer_bytes < skip && spacer_bytes + SPACER <= budget) {
         held.emplace_back();
-        if (make_chunk(device, SPACER, held.back()) != hipSuccess) { held.pop_back(); (void)hipGetLastError(); return; }
+        if (make_spacer(device, SPACER, held.back()) != hipSuccess) { held.pop_back(); (void)hipGetLastError(); return; }
         spacer_bytes += SPACER;
         info.spacer_gib = (double)spacer_bytes / (double)GiB;
     }
@@ -221,7 +238,7 @@ void find_other_zone(int device, size_t budget, size_t skip, std::vector<Range>&
     bool prev_strong = false;
     while (spacer_bytes + SPACER <= budget) {
         held.emplace_back();
-        if (make_chunk(device, SPACER, held.back()) != hipSuccess) { held.pop_back(); (void)hipGetLastError(); break; }
+        if (make_spacer(device, SPACER, held.back()) != hipSuccess) { held.pop_back(); (void)hipGetLastError(); break; }
         spacer_bytes += SPACER;
         info.spacer_gib = (double)spacer_bytes / (double)GiB;
         held.emplace_back();

@@ -19,4 +19,4 @@ cp /tmp/libpogema_oracle_backup.so oracle/libpogema_oracle.so
     -o /tmp/libpogema_amd_asan.so -pthread)
 ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 PGX_LIB=/tmp/libpogema_amd_asan.so \
     LD_PRELOAD=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1) \
-    python -m pytest tests/test_generator.py tests/test_abi.py tests/test_oracle.py tests/test_nprng.py -q -x
+    python -m pytest tests/test_generator.py tests/test_abi.py tests/test_oracle.py tests/test_nprng.py tests/test_npgen.py -q -x

@@ -45,6 +45,18 @@ __global__ __launch_bounds__(64) void zone_probe_kernel(f32x4* __restrict__ lo, 
     f32x4* o = b < half ? lo + (size_t)b * per_block : hi + (size_t)(b - half) * per_block;
     for (size_t i = threadIdx.x; i < per_block; i += 64) o[i] = v;
 }
+// diagnostic twin of the probe: the same chunks READ (sum kept alive through `sink`)
+__global__ __launch_bounds__(64) void zone_read_kernel(const f32x4* __restrict__ lo, const f32x4* __restrict__ hi, size_t per_block,
+                                                        int nblk, float* sink) {
+    const int per_xcd = nblk >> 3;
+    int b = blockIdx.x;
+    if (b < (per_xcd << 3)) b = (b & 7) * per_xcd + (b >> 3);
+    const int half = nblk >> 1;
+    const f32x4* o = b < half ? lo + (size_t)b * per_block : hi + (size_t)(b - half) * per_block;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (size_t i = threadIdx.x; i < per_block; i += 64) acc += __builtin_nontemporal_load(&o[i]);
+    if (acc.x + acc.y + acc.z + acc.w == 12345.f) sink[0] = 1.f;
+}
 }  // namespace pgx
 
 namespace {
@@ -226,6 +238,33 @@ void find_other_zone(int device, size_t budget, size_t skip, std::vector<Range>&
         *found = true;
         return;
     }
+    auto read_diag = [&]() {
+    if (getenv("PGX_ZONE_PAIRS")) {  // diagnostic: how fast does this process READ the same chunks?
+            float* sink = nullptr;
+            if (hipMalloc((void**)&sink, 4) == hipSuccess && held.size() >= 2) {
+                const int nblk = 8192;
+                const size_t per_block = PROBE_HALF / 16 / (nblk / 2);
+                hipEvent_t a, b;
+                (void)hipEventCreate(&a);
+                (void)hipEventCreate(&b);
+                void* hi = held.back().va ? held.back().va : held[1].va;
+                for (int i = 0; i < 2; ++i)
+                    hipLaunchKernelGGL(pgx::zone_read_kernel, dim3(nblk), dim3(64), 0, 0, (const pgx::f32x4*)ref, (const pgx::f32x4*)hi, per_block, nblk, sink);
+                (void)hipEventRecord(a, 0);
+                for (int i = 0; i < 6; ++i)
+                    hipLaunchKernelGGL(pgx::zone_read_kernel, dim3(nblk), dim3(64), 0, 0, (const pgx::f32x4*)ref, (const pgx::f32x4*)hi, per_block, nblk, sink);
+                (void)hipEventRecord(b, 0);
+                (void)hipEventSynchronize(b);
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, a, b);
+                fprintf(stderr, "[pgx_buffers] READ stream over reference + last candidate: %.1f us (%.2f TB/s)\n", ms * 1000.f / 6.f,
+                        2.0 * (double)PROBE_HALF / (ms / 6.0 * 1e-3) / 1e12);
+                (void)hipEventDestroy(a);
+                (void)hipEventDestroy(b);
+                (void)hipFree(sink);
+            }
+        }
+    };
     size_t spacer_bytes = 0;
     // `skip`: a previous attempt ended this far into the walk and its buffers did not deliver -- pass over that stretch
     while (spacer_bytes < skip && spacer_bytes + SPACER <= budget) {
@@ -265,9 +304,11 @@ void find_other_zone(int device, size_t budget, size_t skip, std::vector<Range>&
         if (!getenv("PGX_ZONE_SCAN") && (confirmed || (weak && !strong && (weak_run > WEAK_LIMIT || last)))) {
             info.final_us = t;
             *found = true;
+            read_diag();
             return;
         }
     }
+    read_diag();
     if (getenv("PGX_ZONE_PAIRS")) {  // diagnostic: nothing pairs with the reference -- do the candidates pair with each other?
         std::vector<void*> c;
         for (size_t i = 1; i < held.size(); ++i)

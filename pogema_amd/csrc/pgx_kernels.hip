@@ -424,7 +424,10 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
                 s_vis[tid] = pw;
                 s_want[tid] = qw;
                 lds_sync<true>();
-                for (int sj = 0; sj < nw; ++sj) {  // wave-uniform
+                // partners live in the first ceil(A / 64) waves only: helper waves (num_agents <= 64 on this kernel) hold no
+                // agents, are nobody's partner and skip the sweep themselves
+                const int nwa = (A + 63) >> 6;
+                for (int sj = 0; sj < (wave < nwa ? nwa : 0); ++sj) {  // wave-uniform
                     const bool own = (sj == wave);
                     const uint32_t pj = own ? pw : s_vis[sj * 64 + lane];
                     const uint32_t qj = own ? qw : s_want[sj * 64 + lane];

@@ -383,25 +383,26 @@ class VecPogema:
         # into each of them and into a few buffers as torch's allocator hands them out, keep the fastest n and give
         # the rest back.
         spare = self.SPARE_BUFFERS if self._has_state() else 0
-        pool = ZoneBuffers(self.obs_shape, self.obs_dtype, self.device, count=n + spare)
-        cands = [(self._time_observe(t), i, "zone", t) for i, t in enumerate(pool.tensors)]
-        # The probe's promise, scaled to this tensor: if even the best buffer misses it by 10 % the fast stretch was
-        # narrower than the buffers -- try again further on (at most twice), keep the better pool.
-        attempts = 1
-        while (spare and pool.info["spread"] and attempts < 3 and pool.info["final_us"] > 0 and
-               min(c[0] for c in cands) > float(os.environ.get("PGX_POOL_RETRY", "1.10")) * pool.info["final_us"] * obs_bytes / (2 * (384 << 20))):
-            attempts += 1
-            again = ZoneBuffers(self.obs_shape, self.obs_dtype, self.device, count=n + spare,
-                                skip_gib=pool.info["spacer_gib"] + 16.0)
-            cands2 = [(self._time_observe(t), i, "zone", t) for i, t in enumerate(again.tensors)]
-            if min(c[0] for c in cands2) < min(c[0] for c in cands):
-                pool, cands = again, cands2
-            del again, cands2
-        self.placement = dict(pool.info, method="pgx_buffers (two HBM zones per buffer)", pools_tried=attempts)
+        pools = [ZoneBuffers(self.obs_shape, self.obs_dtype, self.device, count=n + spare)]
+        # candidates: (observation pass [us], order, kind, tensor, pool index, index inside the pool)
+        cands = [(self._time_observe(t), i, "zone", t, 0, i) for i, t in enumerate(pools[0].tensors)]
+        # The probe's promise, scaled to this tensor: if the n-th best buffer misses it by 10 % the fast stretch was
+        # narrower than the buffers -- build another pool further on (at most two more) and choose among all of them.
+        retry = float(os.environ.get("PGX_POOL_RETRY", "1.10"))
+        while spare and len(pools) < 3:
+            info = pools[-1].info
+            nth = sorted(c[0] for c in cands)[n - 1]
+            if not info["spread"] or info["final_us"] <= 0 or nth <= retry * info["final_us"] * obs_bytes / (2 * (384 << 20)):
+                break
+            pools.append(ZoneBuffers(self.obs_shape, self.obs_dtype, self.device, count=n + spare,
+                                     skip_gib=info["spacer_gib"] + 16.0))
+            k = len(pools) - 1
+            cands += [(self._time_observe(t), len(cands) + i, "zone", t, k, i) for i, t in enumerate(pools[k].tensors)]
+        self.placement = dict(pools[0].info, method="pgx_buffers (two HBM zones per buffer)", pools_tried=len(pools))
         if self._has_state():
             k = self.PLAIN_CANDIDATES if obs_bytes < (1 << 30) else self.PLAIN_CANDIDATES // 2
             plain = [torch.empty(self.obs_shape, dtype=self.obs_dtype, device=self.device) for _ in range(k)]
-            cands += [(self._time_observe(t), n + i, "torch", t) for i, t in enumerate(plain)]
+            cands += [(self._time_observe(t), len(cands) + i, "torch", t, -1, -1) for i, t in enumerate(plain)]
             del plain
         cands.sort(key=lambda c: (c[0], c[1]))
         # a plain buffer replaces a pool buffer only when it is clearly faster (2 %): equal times keep the pool
@@ -415,13 +416,15 @@ class VecPogema:
         self.placement.update(chosen=[c[2] for c in chosen], observe_us=[round(c[0], 1) for c in chosen],
                               observe_us_zone=[round(c[0], 1) for c in zone],
                               observe_us_torch_best=round(min((c[0] for c in other), default=0.0), 1))
-        kept = {c[1] for c in chosen if c[2] == "zone"}
+        kept = {(c[4], c[5]) for c in chosen if c[2] == "zone"}
         result = [c[3] for c in chosen]
         self.placement.update(self.tune_xcd_shares(result[0], result[-1] if n > 1 else None))
         del cands, other, zone, chosen
-        for i in range(n + spare):
-            if i not in kept:
-                pool.drop(i)
+        for k, pool in enumerate(pools):  # a pool none of whose buffers is kept dies with its last reference
+            for i in range(n + spare):
+                if (k, i) not in kept:
+                    pool.drop(i)
+        del pools
         torch.cuda.empty_cache()
         return result
 

@@ -420,14 +420,16 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
             const uint32_t wsh = want << 10, im1 = (uint32_t)(i - 1);
             const uint32_t pw = (vis << 10) | (uint32_t)i, qw = wsh | (uint32_t)i;
             const int src = gbase + ((alane + 1) & (G - 1));
-            if constexpr (MW) {
+            // `solo`: a multi-wave workgroup whose agents all sit in wave 0 (num_agents <= 64 with helper waves that only
+            // share the observation write).  Its state phase is the single-wave one -- DPP / bpermute, no LDS exchange,
+            // no barrier; the helper waves run the same code on invalid lanes and simply arrive early at the next barrier.
+            const bool solo = MW && A <= 64;
+            if (MW && !solo) {
                 s_vis[tid] = pw;
                 s_want[tid] = qw;
                 lds_sync<true>();
-                // partners live in the first ceil(A / 64) waves only: helper waves (num_agents <= 64 on this kernel) hold no
-                // agents, are nobody's partner and skip the sweep themselves
-                const int nwa = (A + 63) >> 6;
-                for (int sj = 0; sj < (wave < nwa ? nwa : 0); ++sj) {  // wave-uniform
+                const int nwa = nw;  // every wave holds agents
+                for (int sj = 0; sj < nwa; ++sj) {  // wave-uniform
                     const bool own = (sj == wave);
                     const uint32_t pj = own ? pw : s_vis[sj * 64 + lane];
                     const uint32_t qj = own ? qw : s_want[sj * 64 + lane];
@@ -458,7 +460,7 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
                     // (PGX_SOFT_ALL_STAY): any other claimant blocks.
                     stay = !mover || blocked || (p.soft_rule != 0 ? acc.cany < 1024u : lower);
                     uint32_t want_of_o;
-                    if constexpr (MW) {
+                    if (MW && !solo) {
                         want_of_o = nxt >= 0 ? (s_want[nxt] >> 10) : NOCELL_B;
                     } else {
                         const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute((gbase + (nxt < 0 ? alane : nxt)) << 2, (int)want);
@@ -474,7 +476,7 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
                     const bool open = nxt >= 0 && !stay;
                     const uint32_t packed = (stay ? 0x80000000u : 0u) | (uint32_t)(nxt + 1);
                     uint32_t got;
-                    if constexpr (MW) {
+                    if (MW && !solo) {
                         uint32_t* buf = (it & 1) ? s_x1 : s_x0;
                         buf[tid] = packed;
                         if (__ballot(open) != 0ull && lane == 0) s_misc[MISC_FLAGS + it] = 1u;
@@ -503,7 +505,7 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
             const bool arrived = on_goal && active;  // `was_on_goal` of the reference
             int n_arrived;
             bool solved, all_on_goal;
-            if constexpr (MW) {
+            if (MW && !solo) {
                 const unsigned long long ma = __ballot(arrived);
                 const unsigned long long mu = __ballot(valid && !arrived);
                 const unsigned long long mo = __ballot(valid && !on_goal);

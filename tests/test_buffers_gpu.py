@@ -22,8 +22,9 @@ def test_pool_buffers_are_ordinary_device_memory():
     info = pool.info
     assert info["count"] == 2 and info["bytes"] == a.numel() * 4 and info["same_zone_us"] > 0
     if info["spread"]:
-        # accepted because clearly faster than a same-zone pair, or because at the two-zone rate (>= 6.6 TB/s on 768 MiB)
-        assert info["final_us"] < 0.9 * info["same_zone_us"] or info["final_us"] <= 122.1
+        # accepted because faster than a same-zone pair (the walk's weak criterion: 6 %), or because at the two-zone rate
+        # (>= 6.6 TB/s on 768 MiB)
+        assert info["final_us"] < 0.94 * info["same_zone_us"] or info["final_us"] <= 122.1
     # the memory outlives the pool object for as long as a tensor references it
     del pool, b
     a.add_(1.0)

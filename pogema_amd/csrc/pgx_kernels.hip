@@ -257,6 +257,10 @@ __device__ __forceinline__ void stream_obs_u8(uint8_t* out, size_t base, int n, 
 //                 agents [64w, 64w+64).  Every wave resolves its own agents against all A partners
 //                 (partners of other waves come from LDS, then the same DPP rotation), the
 //                 transitive closure and the env-wide reductions go through LDS.
+//                 The same kernel also runs environments of <= 64 agents with HELPER waves (step_geometry(): small
+//                 launches of large environments; three waves for large launches of 64-agent environments): wave 0
+//                 holds the agents and runs the single-wave state phase, the other waves only share the row masks
+//                 and the observation write.
 //   P16         : window side <= 16: row masks are packed to 16 bits, staged through registers and
 //                 written OVER the (by then dead) bitmaps and exchange arrays, so the LDS footprint is
 //                 max(state, rows) and many waves stay resident per CU (DESIGN.md "occupancy").

@@ -373,10 +373,12 @@ int pgx_buffers_create_at(int device, size_t bytes, int count, double skip_gib, 
         const hipError_t e = map_part(device, p->va_of(i), p->first, p->all.parts[2 * i]);
         if (e != hipSuccess) return bail(code_of(e), "hipMemCreate/hipMemMap (first half)", e);
     }
-    // 2. walk the allocator into another zone.  Buffers below 256 MiB are left alone: a repeated stream of that size is
-    //    absorbed by the Infinity Cache and too short to be bandwidth-bound (configs[3], 190 MB: +-2 % either way).
+    // 2. walk the allocator into another zone.  Buffers below 128 MiB are left alone: a repeated stream of that size is
+    //    absorbed by the 256 MiB Infinity Cache and too short to be bandwidth-bound (configs[3]'s 190 MB buffers: two
+    //    alternating ones exceed the cache together, the spread is worth 2-3 %).
     bool found = false;
-    if (p->second && total >= ((size_t)256 << 20) && max_spacer_gib > 0.0) {
+    const size_t walk_min = getenv("PGX_ZONE_MIN_MB") ? (size_t)atol(getenv("PGX_ZONE_MIN_MB")) << 20 : (size_t)128 << 20;
+    if (p->second && total >= walk_min && max_spacer_gib > 0.0) {
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
         const size_t need = (size_t)count * p->second + 20 * PROBE_HALF + 4 * GiB;
@@ -400,7 +402,7 @@ int pgx_buffers_create_at(int device, size_t bytes, int count, double skip_gib, 
     // What the buffers themselves sustain (slowest one), for the record only: the probe's 8192 chunks grow with the
     // buffer, and beyond ~1 GB this stream shape saturates near 6.1 TB/s wherever the pages are (configs[4]: the
     // step kernel runs 23 % faster on spread buffers while this figure does not move), so it is not used as a judge.
-    if (p->second && total >= ((size_t)256 << 20)) {
+    if (p->second && total >= walk_min) {
         double worst = 0.0;
         for (int i = 0; i < count; ++i) {
             float t = 0.f;

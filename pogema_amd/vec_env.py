@@ -364,9 +364,10 @@ class VecPogema:
     # another zone ~6.9 TB/s (DESIGN.md "placement", profiles/r2/placement_*.txt).  A plain allocation is physically
     # compact -- one zone, unless it straddles a boundary by luck (round 1 searched for such lucky buffers by timing up
     # to 64 candidates).  The engine's buffer pool (pgx_buffers_create) REQUESTS the placement instead: each buffer is
-    # one virtual range whose second half is backed by another zone, verified by timing.  Buffers below 256 MiB (a
-    # repeated stream of that size is absorbed by the Infinity Cache; configs[3]: +-2 %) come from torch's allocator.
-    PLACEMENT_MIN_BYTES = 256 << 20
+    # one virtual range whose second half is backed by another zone, verified by timing.  Buffers below 128 MiB (a
+    # repeated stream of that size is absorbed by the Infinity Cache) come from torch's allocator; configs[3]'s two
+    # alternating 190 MB buffers exceed the cache together and gain 2-3 % from the pool.
+    PLACEMENT_MIN_BYTES = int(os.environ.get("PGX_ZONE_MIN_MB", "128")) << 20
 
     def _pick_obs_buffers(self):
         obs_bytes = int(np.prod(self.obs_shape)) * (4 if self.obs_dtype == torch.float32 else 1)
@@ -540,7 +541,7 @@ class VecPogema:
         same outputs -- for callers that have the actions up front (MAPF plans, scripted / random policies, replays).
         `actions`: int tensor [K, batch, agents].  `obs_slots`: how many observation tensors to keep -- None = K (the whole
         trajectory, K x obs bytes of HBM), n >= 1: a ring, step t lands in slot t % n (1 = only the last one), 0 = none.
-        A ring of up to 8 slots of >= 256 MiB each is taken from the engine's zone-spread buffers (`placement` as for
+        A ring of up to 8 slots of >= 128 MiB each is taken from the engine's zone-spread buffers (`placement` as for
         `reuse_buffers`), kept by the env and OVERWRITTEN BY THE NEXT rollout() with the same `obs_slots`; its first axis is
         strided (slot stride = bytes rounded up to 2 MiB), every slot itself is contiguous.
         Returns a dict of device tensors: obs [slots, batch, agents, 3, W, W] (or None), rewards f32 / terminated /
@@ -583,9 +584,20 @@ class VecPogema:
                     # two buffers more than needed; the run of `slots` consecutive ones into which the observation
                     # stream itself is fastest becomes the ring, the others are given back (see _pick_obs_buffers)
                     from .buffers import ZoneBuffers
-                    pool = ZoneBuffers(self.obs_shape, self.obs_dtype, dev, count=slots + 2)
-                    times = [self._time_observe(t) for t in pool.tensors]
-                    start = min(range(3), key=lambda s: (max(times[s:s + slots]), s))
+                    retry = float(os.environ.get("PGX_POOL_RETRY", "1.10"))
+                    pool, times, start, skip = None, None, 0, 0.0
+                    for _ in range(3):  # as in _pick_obs_buffers: try further on while the ring misses the probe's promise
+                        cand = ZoneBuffers(self.obs_shape, self.obs_dtype, dev, count=slots + 2, skip_gib=skip)
+                        ct = [self._time_observe(t) for t in cand.tensors]
+                        cs = min(range(3), key=lambda s: (max(ct[s:s + slots]), s))
+                        if pool is None or max(ct[cs:cs + slots]) < max(times[start:start + slots]):
+                            pool, times, start = cand, ct, cs
+                        info = cand.info
+                        del cand
+                        if (not info["spread"] or info["final_us"] <= 0 or
+                                max(times[start:start + slots]) <= retry * info["final_us"] * obs_bytes / (2 * (384 << 20))):
+                            break
+                        skip = info["spacer_gib"] + 16.0
                     ring = pool.ring_view(start, slots)
                     for i in range(slots + 2):
                         if not start <= i < start + slots:

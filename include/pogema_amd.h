@@ -287,7 +287,7 @@ int pgx_time_observe(pgx_env* env, void* obs, int32_t reps, float* microseconds,
  * contiguous virtual range (HIP virtual-memory API) whose second half is backed by physical memory from another zone:
  * the allocator is walked there with temporary spacer allocations (at most `max_spacer_gib` GiB and 90 % of the free
  * memory, released before the call returns) and every candidate is verified by timing a store stream into the buffer.
- * Buffers below 256 MiB are returned without a walk.  The walk assumes that the allocator hands out memory roughly in
+ * Buffers below 128 MiB are returned without a walk.  The walk assumes that the allocator hands out memory roughly in
  * address order (true for a process that has not fragmented its HBM); when it finds nothing, the buffers are valid but
  * not spread and `spread` says so.  The call synchronises the device (it times kernels on the default stream); ~0.1-2 s.
  *   max_spacer_gib <= 0  no search: the halves come from wherever the allocator is (still valid buffers)
@@ -302,7 +302,7 @@ typedef struct pgx_buffers_info {
     float same_zone_us;   /* probe stream (768 MiB) into two halves allocated back to back (same zone)       */
     float final_us;       /* probe stream with the second half taken where the buffers' second halves are      */
     double spacer_gib;    /* spacer memory held at the end of the search (released before returning)          */
-    float buffer_gbs;     /* store-stream rate into the slowest buffer as returned (0 below 256 MiB: no walk --  */
+    float buffer_gbs;     /* store-stream rate into the slowest buffer as returned (0 below 128 MiB: no walk --  */
                           /* such a stream is absorbed by the Infinity Cache and says nothing about placement)  */
     float reserved1;
 } pgx_buffers_info;

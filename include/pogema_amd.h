@@ -277,6 +277,9 @@ int pgx_observe(pgx_env* env, void* obs, void* stream);
  * that owns a pool of candidate buffers can keep the well-placed ones (VecPogema(reuse_buffers=True) does).
  * Synchronises `stream`.  Nothing in the engine's state changes. */
 int pgx_time_observe(pgx_env* env, void* obs, int32_t reps, float* microseconds, void* stream);
+/* The same into `obs` and `obs_alt` in turn -- how a caller with two alternating output buffers writes.  Two buffers that
+ * together exceed the 256 MiB Infinity Cache behave differently from one buffer that fits it. */
+int pgx_time_observe_pair(pgx_env* env, void* obs, void* obs_alt, int32_t reps, float* microseconds, void* stream);
 
 /* ---- zone-aware output buffers ------------------------------------------------------------------ */
 /* Nothing in the reference corresponds to this: it is where the caller-owned observation buffers SHOULD live on an

@@ -51,7 +51,7 @@ EXPORTED_SYMBOLS = (
     "pgx_reset_from_state", "pgx_reset_random", "pgx_regenerate", "pgx_regenerate_failures", "pgx_get_map", "pgx_step", "pgx_observe", "pgx_set_metrics_buffers", "pgx_get_state", "pgx_generate", "pgx_place_agents",
     "pgx_snapshot_bytes", "pgx_save_snapshot", "pgx_load_snapshot", "pgx_time_observe", "pgx_bad_action_count",
     "pgx_buffers_create", "pgx_buffers_ptr", "pgx_buffers_get_info", "pgx_buffers_destroy", "pgx_set_targets",
-    "pgx_np_streams", "pgx_np_streams_host", "pgx_np_generate", "pgx_np_generate_host", "pgx_rollout", "pgx_buffers_stride", "pgx_buffers_drop", "pgx_xcd_shares", "pgx_xcd_tune", "pgx_buffers_create_at",
+    "pgx_np_streams", "pgx_np_streams_host", "pgx_np_generate", "pgx_np_generate_host", "pgx_rollout", "pgx_buffers_stride", "pgx_buffers_drop", "pgx_xcd_shares", "pgx_xcd_tune", "pgx_buffers_create_at", "pgx_time_observe_pair",
 )
 
 
@@ -154,6 +154,8 @@ def load() -> C.CDLL:
     lib.pgx_bad_action_count.restype = i64
     lib.pgx_time_observe.argtypes = [vp, vp, i32, C.POINTER(C.c_float), vp]
     lib.pgx_time_observe.restype = C.c_int
+    lib.pgx_time_observe_pair.argtypes = [vp, vp, vp, i32, C.POINTER(C.c_float), vp]
+    lib.pgx_time_observe_pair.restype = C.c_int
     lib.pgx_snapshot_bytes.argtypes = [vp]
     lib.pgx_snapshot_bytes.restype = i64
     lib.pgx_save_snapshot.argtypes = [vp, vp, vp]

@@ -417,6 +417,16 @@ class VecPogema:
         self.placement.update(chosen=[c[2] for c in chosen], observe_us=[round(c[0], 1) for c in chosen],
                               observe_us_zone=[round(c[0], 1) for c in zone],
                               observe_us_torch_best=round(min((c[0] for c in other), default=0.0), 1))
+        if n == 2 and len(other) >= 2 and any(c[2] == "zone" for c in chosen):
+            # what counts is the PAIR written in turn (two buffers that together exceed the Infinity Cache behave
+            # differently from one that fits it, and single-buffer timings of < 256 MiB tensors all look alike):
+            # the chosen pair against two of torch's own buffers
+            pair_chosen = self._time_observe(chosen[0][3], chosen[1][3])
+            pair_plain = self._time_observe(other[0][3], other[1][3])
+            self.placement.update(observe_pair_us=round(pair_chosen, 1), observe_pair_us_torch=round(pair_plain, 1))
+            if pair_plain < 0.98 * pair_chosen:
+                chosen = other[:2]
+                self.placement.update(chosen=[c[2] for c in chosen], observe_us=[round(c[0], 1) for c in chosen])
         kept = {(c[4], c[5]) for c in chosen if c[2] == "zone"}
         result = [c[3] for c in chosen]
         self.placement.update(self.tune_xcd_shares(result[0], result[-1] if n > 1 else None))
@@ -444,11 +454,15 @@ class VecPogema:
     PLAIN_CANDIDATES = 8
     SPARE_BUFFERS = 4
 
-    def _time_observe(self, obs: torch.Tensor) -> float:
-        """Average duration [us] of the observation stream into `obs` (pgx_time_observe; needs an installed state)."""
+    def _time_observe(self, obs: torch.Tensor, obs_alt: Optional[torch.Tensor] = None) -> float:
+        """Average duration [us] of the observation stream into `obs` -- or into `obs` and `obs_alt` in turn
+        (pgx_time_observe_pair; needs an installed state)."""
         if not self._has_state():
             return 0.0
         us = C.c_float(0.0)
+        if obs_alt is not None:
+            _lib.check(self._lib.pgx_time_observe_pair(self._handle, obs.data_ptr(), obs_alt.data_ptr(), 8, C.byref(us), self._stream()))
+            return float(us.value)
         _lib.check(self._lib.pgx_time_observe(self._handle, obs.data_ptr(), 3, C.byref(us), self._stream()))
         return float(us.value)
 

@@ -28,6 +28,22 @@ def _as_device_index(device) -> int:
     return dev.index if dev.index is not None else torch.cuda.current_device()
 
 
+def choose_buffers(zone_us, plain_us, n, margin=0.98):
+    """Which n of the timed candidates to keep: the n fastest pool ('zone') buffers, each replaced by one of the
+    allocator's own ('torch') buffers only where that one is clearly faster (by more than 1 - margin) than the slowest
+    pool buffer still chosen -- equal times keep the pool.  Both lists sorted ascending; returns [(kind, index), ...]."""
+    chosen = [("zone", i) for i in range(min(n, len(zone_us)))]
+    time_of = {"zone": zone_us, "torch": plain_us}
+    for j, t in enumerate(plain_us):
+        if len(chosen) < n:
+            chosen.append(("torch", j))
+            continue
+        worst = max(chosen, key=lambda c: time_of[c[0]][c[1]])
+        if t < margin * time_of[worst[0]][worst[1]]:
+            chosen[chosen.index(worst)] = ("torch", j)
+    return chosen
+
+
 class VecPogema:
     """`batch` independent POGEMA environments on one MI355X.
 
@@ -406,14 +422,10 @@ class VecPogema:
             cands += [(self._time_observe(t), len(cands) + i, "torch", t, -1, -1) for i, t in enumerate(plain)]
             del plain
         cands.sort(key=lambda c: (c[0], c[1]))
-        # a plain buffer replaces a pool buffer only when it is clearly faster (2 %): equal times keep the pool
         zone = [c for c in cands if c[2] == "zone"]
         other = [c for c in cands if c[2] != "zone"]
-        chosen = zone[:n]
-        for c in other:
-            worst = max(chosen, key=lambda z: z[0])
-            if c[0] < 0.98 * worst[0]:
-                chosen[chosen.index(worst)] = c
+        picks = choose_buffers([c[0] for c in zone], [c[0] for c in other], n)
+        chosen = [(zone if kind == "zone" else other)[i] for kind, i in picks]
         self.placement.update(chosen=[c[2] for c in chosen], observe_us=[round(c[0], 1) for c in chosen],
                               observe_us_zone=[round(c[0], 1) for c in zone],
                               observe_us_torch_best=round(min((c[0] for c in other), default=0.0), 1))

@@ -563,7 +563,10 @@ def main(argv=None):
                          "kernel_ms_windows": kernel,
                          "default_placement_kernel_ms": default_ms,
                          "box_store_stream_gbs": None if args.stub else step.box_store_stream_gbs(),
-                         "algorithmic_bytes_per_agent_step": bpas, "algorithmic_bytes_per_launch": alg_bytes},
+                         "algorithmic_bytes_per_agent_step": bpas, "algorithmic_bytes_per_launch": alg_bytes,
+                         "profile_command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-default-placement "
+                                            "--no-cpu-baseline --no-extras  (the default-placement window and the secondary "
+                                            "figures launch the same kernel on other buffers / half batches; profiles/r2/README.md)"},
         }
         if "pipelined" in extras:
             e = extras["pipelined"]

@@ -188,8 +188,10 @@ class EngineStep:
                              auto_reset=True if args.auto_reset == "restore" else "regenerate",
                              reuse_buffers=True if args.buffers == 2 else "single",
                              obs_dtype=torch.float32 if args.obs_dtype == "float32" else torch.uint8,
-                             placement_probe=placement_probe)
+                             placement_probe=placement_probe,
+                             placement_budget_gib="all")  # this process owns the device: the zone walk may use all of it
         self.env.reset(seed=0)
+        self.env.warm_buffers()  # zone walk + candidate timing + XCD shares here, not inside the first timed step
         tdt = {"int8": torch.int8, "int32": torch.int32, "int64": torch.int64}[args.action_dtype]
         gen = torch.Generator(device=device)
         gen.manual_seed(1 + rank)
@@ -261,9 +263,10 @@ class PipelinedStep:
                         collision_system=args.collision, on_target=args.on_target,
                         max_episode_steps=args.max_episode_steps)
         self.env = PipelinedVecPogema(gc, batch=batch, device=device, parts=parts, env_index_base=env_base, auto_reset=True,
-                                      reuse_buffers=True,
+                                      reuse_buffers=True, placement_budget_gib="all",
                                       obs_dtype=torch.float32 if args.obs_dtype == "float32" else torch.uint8)
         self.env.reset(seed=0)
+        self.env.warm_buffers()
         tdt = {"int8": torch.int8, "int32": torch.int32, "int64": torch.int64}[args.action_dtype]
         gen = torch.Generator(device=device)
         gen.manual_seed(1 + rank)
@@ -306,6 +309,7 @@ class RolloutStep:
                         collision_system=args.collision, on_target=args.on_target,
                         max_episode_steps=args.max_episode_steps)
         self.env = VecPogema(gc, batch=batch, device=device, env_index_base=env_base, auto_reset=True,
+                             placement_budget_gib="all",
                              obs_dtype=torch.float32 if args.obs_dtype == "float32" else torch.uint8)
         self.env.reset(seed=0)
         tdt = {"int8": torch.int8, "int32": torch.int32, "int64": torch.int64}[args.action_dtype]
@@ -538,11 +542,18 @@ def main(argv=None):
                     traffic = json.load(f).get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        headline = args.workload == "cfg2" and args.obs_dtype == "float32" and not args.stub
+        # BASELINE.json's metric label only for BASELINE.json's workload as the product runs it: configs[2], float32,
+        # 8192 envs on every GPU, one launch per step into two alternating buffers, observations written
+        headline = (args.workload == "cfg2" and args.obs_dtype == "float32" and not args.stub and batch == per_gpu
+                    and args.global_batch == 0 and args.buffers == 2 and args.graph == 0 and not args.no_obs)
+        variant = "".join([f", {batch} envs per GPU" if args.global_batch == 0 else f", global batch {total_envs}",
+                           ", one output buffer" if args.buffers == 1 else "",
+                           f", hipGraph of {args.graph} steps" if args.graph > 0 else "",
+                           ", NO observation write (diagnostic)" if args.no_obs else ""])
         line = {
             "metric": "agent-steps/sec (whole node), 64-agent 64x64 grid, batch=8192 envs" if headline
                       else f"{'STUB (not a measurement) ' if args.stub else ''}agent-steps/sec (whole node), "
-                           f"workload {args.workload}, obs {args.obs_dtype}",
+                           f"workload {args.workload}, obs {args.obs_dtype}{variant}",
             "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "u32", "data": "stub" if args.stub else "synthetic",

@@ -292,7 +292,10 @@ int pgx_time_observe_pair(pgx_env* env, void* obs, void* obs_alt, int32_t reps, 
  * memory, released before the call returns) and every candidate is verified by timing a store stream into the buffer.
  * Buffers below 128 MiB are returned without a walk.  The walk assumes that the allocator hands out memory roughly in
  * address order (true for a process that has not fragmented its HBM); when it finds nothing, the buffers are valid but
- * not spread and `spread` says so.  The call synchronises the device (it times kernels on the default stream); ~0.1-2 s.
+ * not spread and `spread` says so.  The call blocks the calling thread for ~0.1-2 s (it times kernels on a private
+ * non-blocking stream; work the caller has in flight on the device perturbs the timings, so callers synchronise first).
+ * WHILE IT RUNS, up to min(max_spacer_gib, 90 % of the free memory) of HBM is held: on a device shared with other
+ * processes pass a budget that leaves them room (the Python host defaults to half of the free memory).
  *   max_spacer_gib <= 0  no search: the halves come from wherever the allocator is (still valid buffers)
  * Buffers are usable by any kernel / copy like hipMalloc'd memory and stay valid until pgx_buffers_destroy. */
 typedef struct pgx_buffers pgx_buffers; /* opaque */
@@ -322,6 +325,11 @@ int pgx_buffers_drop(pgx_buffers* pool, int index);  /* releases the memory of O
                                                         than it needs, time its own stream into each and keep the best */
 int pgx_buffers_get_info(pgx_buffers* pool, pgx_buffers_info* info);
 int pgx_buffers_destroy(pgx_buffers* pool);          /* synchronises the device, then unmaps and frees        */
+/* Address space (bytes) this process has reserved for pool buffers so far.  These ranges are never handed back to the
+ * driver nor re-used (ROCm 7.2 keeps stale translations either way: DESIGN.md 4b, profiles/r3/vmm_va_remap_stale.txt),
+ * so the figure grows by count x stride with every pool -- out of 128 TiB; a caller that builds pools in a loop can
+ * watch it here.  The probe chunks of the zone walk are plain hipMalloc memory and do not count. */
+int64_t pgx_buffers_va_reserved(void);
 
 /* ---- numpy-compatible random primitives ----------------------------------------------------------- */
 /* Upstream POGEMA draws everything random from numpy Generators (np.random.default_rng(seed): SeedSequence -> PCG64 ->

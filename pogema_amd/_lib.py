@@ -51,7 +51,7 @@ EXPORTED_SYMBOLS = (
     "pgx_reset_from_state", "pgx_reset_random", "pgx_regenerate", "pgx_regenerate_failures", "pgx_get_map", "pgx_step", "pgx_observe", "pgx_set_metrics_buffers", "pgx_get_state", "pgx_generate", "pgx_place_agents",
     "pgx_snapshot_bytes", "pgx_save_snapshot", "pgx_load_snapshot", "pgx_time_observe", "pgx_bad_action_count",
     "pgx_buffers_create", "pgx_buffers_ptr", "pgx_buffers_get_info", "pgx_buffers_destroy", "pgx_set_targets",
-    "pgx_np_streams", "pgx_np_streams_host", "pgx_np_generate", "pgx_np_generate_host", "pgx_rollout", "pgx_buffers_stride", "pgx_buffers_drop", "pgx_xcd_shares", "pgx_xcd_tune", "pgx_buffers_create_at", "pgx_time_observe_pair",
+    "pgx_np_streams", "pgx_np_streams_host", "pgx_np_generate", "pgx_np_generate_host", "pgx_rollout", "pgx_buffers_stride", "pgx_buffers_drop", "pgx_xcd_shares", "pgx_xcd_tune", "pgx_buffers_create_at", "pgx_time_observe_pair", "pgx_buffers_va_reserved",
 )
 
 
@@ -144,6 +144,8 @@ def load() -> C.CDLL:
     lib.pgx_xcd_shares.restype = C.c_int
     lib.pgx_buffers_drop.argtypes = [vp, i32]
     lib.pgx_buffers_drop.restype = C.c_int
+    lib.pgx_buffers_va_reserved.argtypes = []
+    lib.pgx_buffers_va_reserved.restype = C.c_int64
     lib.pgx_buffers_stride.argtypes = [vp]
     lib.pgx_buffers_stride.restype = C.c_int64
     lib.pgx_rollout.argtypes = [vp, i32, C.POINTER(PgxRolloutIO), vp]

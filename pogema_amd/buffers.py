@@ -46,8 +46,21 @@ class ZoneBuffers:
 
     max_spacer_gib: memory the search may hold temporarily while it walks the allocator into another zone (released
     before the constructor returns; the engine additionally keeps 10 % of the free memory untouched).  The next zone can
-    be 40 ... > 128 GiB away from where the allocator stands (profiles/r2/placement_walk_scan.txt), so the default lets
-    the walk use all free memory: PGX_ZONE_SPACER_GIB or 272; 0 disables the search.  PGX_DEBUG=1 traces the walk."""
+    be 40 ... > 128 GiB away from where the allocator stands (profiles/r2/placement_walk_scan.txt).  While the walk runs
+    (~1-2 s) that memory is unavailable to everybody else on the device, so the DEFAULT is bounded: PGX_ZONE_SPACER_GIB
+    if set, otherwise half of the memory that is free right now (`default_spacer_gib`); a caller that owns the device
+    (bench.py) passes "all" (= up to 272 GiB, i.e. everything the engine's own 10 % reserve leaves); 0 disables the
+    search.  PGX_DEBUG=1 traces the walk."""
+
+    ALL_GIB = 272.0
+
+    @staticmethod
+    def default_spacer_gib(index: int) -> float:
+        env = os.environ.get("PGX_ZONE_SPACER_GIB")
+        if env is not None:
+            return float(env)
+        free, _total = torch.cuda.mem_get_info(index)
+        return min(ZoneBuffers.ALL_GIB, 0.5 * free / float(1 << 30))
 
     def __init__(self, shape, dtype, device, count=2, max_spacer_gib=None, skip_gib=0.0):
         if dtype not in _TYPESTR:
@@ -55,11 +68,13 @@ class ZoneBuffers:
         dev = torch.device(device)
         index = dev.index if dev.index is not None else torch.cuda.current_device()
         if max_spacer_gib is None:
-            max_spacer_gib = float(os.environ.get("PGX_ZONE_SPACER_GIB", "272"))
+            max_spacer_gib = self.default_spacer_gib(index)
+        elif max_spacer_gib == "all":
+            max_spacer_gib = float(os.environ.get("PGX_ZONE_SPACER_GIB", self.ALL_GIB))
         lib = _lib.load()
         nbytes = int(np.prod(shape)) * (4 if dtype == torch.float32 else 1)
         handle = C.c_void_p()
-        torch.cuda.synchronize(index)  # the search times kernels on the default stream
+        torch.cuda.synchronize(index)  # the search times kernels (on a private stream): nothing else should be running
         _lib.check(lib.pgx_buffers_create_at(index, nbytes, int(count), float(skip_gib), float(max_spacer_gib), C.byref(handle)))
         self._owner = _Owner(lib, handle)
         info = _lib.PgxBuffersInfo()
@@ -67,7 +82,7 @@ class ZoneBuffers:
         self.info = {"spread": bool(info.spread), "candidates": int(info.candidates),
                      "same_zone_us": round(float(info.same_zone_us), 2), "final_us": round(float(info.final_us), 2),
                      "spacer_gib": float(info.spacer_gib), "bytes": int(info.bytes), "count": int(info.count),
-                     "buffer_gbs": round(float(info.buffer_gbs), 1)}
+                     "buffer_gbs": round(float(info.buffer_gbs), 1), "budget_gib": round(float(max_spacer_gib), 1)}
         self.tensors = []
         for i in range(count):
             ptr = lib.pgx_buffers_ptr(handle, i)

@@ -181,6 +181,7 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
             const std::string v = f;
             g->store_policy = v == "plain" ? 0 : v == "nt" ? 1 : v == "sc1" ? 2 : g->store_policy;
         }
+        if (const char* f = getenv("PGX_STATE_STORES")) g->state_stores = atoi(f);  // tuning/diagnostic override: 0 | 1 | 2
         if (const char* f = getenv("PGX_LDS_MIN")) {  // diagnostic: cap residency by reserving LDS per workgroup
             const size_t m = (size_t)atol(f);
             if (m > g->lds_bytes) g->lds_bytes = (m + 15) & ~(size_t)15;
@@ -601,6 +602,7 @@ static void fill_params(const pgx_env* e, pgx::StepParams& p) {
     p.epw = e->geo.epw;
     p.stagger = e->geo.stagger;
     p.store_policy = e->geo.store_policy;
+    p.state_stores = e->geo.state_stores;
     for (int x = 0; x < 8; ++x) {
         p.xcd_n[x] = e->geo.xcd_n[x];
         p.xcd_base[x] = e->geo.xcd_base[x];
@@ -697,6 +699,7 @@ int pgx_rollout(pgx_env* e, int32_t steps, const pgx_rollout_io* io, void* strea
     p.epw = e->geo_roll.epw;
     p.stagger = e->geo_roll.stagger;
     p.store_policy = e->geo_roll.store_policy;
+    p.state_stores = e->geo_roll.state_stores;
     for (int x = 0; x < 8; ++x) {
         p.xcd_n[x] = e->geo_roll.xcd_n[x];
         p.xcd_base[x] = e->geo_roll.xcd_base[x];

@@ -20,6 +20,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -115,30 +117,85 @@ void drop_part(Part& part) {
     part.live = false;
 }
 
+// Address ranges of the VMM API are never given back to the driver (hipMemAddressFree) NOR re-used for new memory:
+//  * ROCm 7.2: a range that is freed, reserved again at the same address and mapped to new memory can keep answering
+//    with its OLD translation -- stores that never arrive, then "Memory access fault by GPU"
+//    (tools/vmm_ring_repro.py: 2 of 2 runs within 6 pools; 0 of 36 pools with the ranges kept; profiles/r2/vmm_va_reuse_fault.txt);
+//  * round 3 tried the gentler form -- keep the reservation, hipMemUnmap, hipMemMap a fresh handle at the same address
+//    (a process-wide free list of released ranges): the 12th pool of 2.8 GB buffers read back wrong data
+//    (tools/vmm_va_reuse_check.py, profiles/r3/vmm_va_remap_stale.txt) -- some XCD still held the old translation.
+// So a pool's own ranges leak address space (count x stride per pool out of 128 TiB; pgx_buffers_va_reserved() reports
+// the total), and everything that does NOT need two physical halves behind one address -- the probe chunks of the zone
+// walk, ~13 GiB per walk -- is plain hipMalloc/hipFree memory, whose addresses the runtime recycles safely.
+// PGX_VA_REUSE=1 switches the free list on, PGX_VA_FREE=1 the hipMemAddressFree (diagnostics for later ROCm versions).
+std::mutex g_va_mu;
+std::multimap<size_t, void*> g_va_free;  // PGX_VA_REUSE=1 only: reserved, fully unmapped ranges by size
+size_t g_va_reserved = 0;               // bytes of address space this process has reserved so far (pgx_buffers_va_reserved)
+
+bool va_reuse() {
+    static const bool on = [] { const char* e = getenv("PGX_VA_REUSE"); return e && e[0] == '1'; }();
+    return on;
+}
+
 // a virtual range that owns its parts
 struct Range {
     void* va = nullptr;
     size_t bytes = 0;
+    bool plain = false;  // `va` is a hipMalloc allocation (probe chunks), not a VMM reservation
     std::vector<Part> parts;
     hipError_t reserve(size_t n) {
         bytes = n;
+        if (va_reuse()) {
+            std::lock_guard<std::mutex> lock(g_va_mu);
+            auto it = g_va_free.find(n);
+            if (it != g_va_free.end()) {
+                va = it->second;
+                g_va_free.erase(it);
+                return hipSuccess;
+            }
+        }
         const hipError_t e = hipMemAddressReserve(&va, n, GRANULE, nullptr, 0);
         if (e != hipSuccess) va = nullptr;
+        else {
+            std::lock_guard<std::mutex> lock(g_va_mu);
+            g_va_reserved += n;
+        }
         return e;
     }
     void release() {
+        if (plain) {
+            if (va) (void)hipFree(va);
+            va = nullptr;
+            plain = false;
+            return;
+        }
         for (Part& p : parts) drop_part(p);
         parts.clear();
-        // The address range itself is NOT given back (hipMemAddressFree): on ROCm 7.2 a range that is freed, reserved
-        // again at the same address and mapped to new memory can keep answering with its OLD translation -- stores that
-        // never arrive, then "Memory access fault by GPU" (tools/vmm_ring_repro.py: 2 of 2 runs within 6 pools; 0 of 36
-        // pools with the ranges kept).  Only address space leaks: the buffers' own ranges and ~13 GiB of probe chunks
-        // per zone walk out of 128 TiB (the spacers are never mapped).
-        // PGX_VA_FREE=1 restores the free (diagnostic).
         if (va && getenv("PGX_VA_FREE")) (void)hipMemAddressFree(va, bytes);
+        else if (va && va_reuse()) {
+            std::lock_guard<std::mutex> lock(g_va_mu);
+            g_va_free.emplace(bytes, va);
+        }
         va = nullptr;
     }
 };
+
+// The probes run on a private NON-BLOCKING stream per device: the legacy null stream would synchronise implicitly with
+// every blocking stream of the process.  Created once per device, kept for the life of the process.
+hipStream_t probe_stream(int device) {
+    static std::mutex mu;
+    static std::map<int, hipStream_t> streams;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = streams.find(device);
+    if (it != streams.end()) return it->second;
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        s = nullptr;  // fall back to the null stream
+    }
+    streams[device] = s;
+    return s;
+}
 
 }  // namespace
 
@@ -155,7 +212,7 @@ struct pgx_buffers {
 namespace {
 
 // average duration of the probe stream: `half_bytes` into `lo` and `half_bytes` into `hi`, concurrently
-hipError_t probe_us(void* lo, void* hi, size_t half_bytes, float* us) {
+hipError_t probe_us(hipStream_t st, void* lo, void* hi, size_t half_bytes, float* us) {
     const int nblk = 8192;
     const size_t per_block = half_bytes / 16 / (nblk / 2);
     hipEvent_t a, b;
@@ -169,11 +226,11 @@ hipError_t probe_us(void* lo, void* hi, size_t half_bytes, float* us) {
     (void)hipGetLastError();
     const int reps = 6;
     for (int i = 0; i < 2; ++i)
-        hipLaunchKernelGGL(pgx::zone_probe_kernel, dim3(nblk), dim3(64), 0, 0, (pgx::f32x4*)lo, (pgx::f32x4*)hi, per_block, nblk);
-    (void)hipEventRecord(a, 0);
+        hipLaunchKernelGGL(pgx::zone_probe_kernel, dim3(nblk), dim3(64), 0, st, (pgx::f32x4*)lo, (pgx::f32x4*)hi, per_block, nblk);
+    (void)hipEventRecord(a, st);
     for (int i = 0; i < reps; ++i)
-        hipLaunchKernelGGL(pgx::zone_probe_kernel, dim3(nblk), dim3(64), 0, 0, (pgx::f32x4*)lo, (pgx::f32x4*)hi, per_block, nblk);
-    (void)hipEventRecord(b, 0);
+        hipLaunchKernelGGL(pgx::zone_probe_kernel, dim3(nblk), dim3(64), 0, st, (pgx::f32x4*)lo, (pgx::f32x4*)hi, per_block, nblk);
+    (void)hipEventRecord(b, st);
     e = hipEventSynchronize(b);
     float ms = 0.f;
     if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
@@ -189,8 +246,21 @@ void destroy(pgx_buffers* p) {
     delete p;
 }
 
-// one allocation of `bytes` at its own virtual address, accessible
+// one allocation of `bytes` at its own virtual address, accessible: a probe chunk of the zone walk.  Plain hipMalloc
+// memory (the same VRAM allocator as hipMemCreate, so it marks where the allocator stands just as well) whose address
+// the runtime takes back on hipFree -- see the note on address ranges above.  PGX_CHUNK_VMM=1: the round-2 form
+// (VMM handle mapped into a reservation that is then leaked), for A/B.
 hipError_t make_chunk(int device, size_t bytes, Range& r) {
+    static const bool vmm = getenv("PGX_CHUNK_VMM") != nullptr;
+    if (!vmm) {
+        void* ptr = nullptr;
+        const hipError_t e = hipMalloc(&ptr, bytes);
+        if (e != hipSuccess) return e;
+        r.va = ptr;
+        r.bytes = bytes;
+        r.plain = true;
+        return hipSuccess;
+    }
     hipError_t e = r.reserve(bytes);
     if (e != hipSuccess) return e;
     r.parts.resize(1);
@@ -223,13 +293,14 @@ hipError_t make_spacer(int device, size_t bytes, Range& r) {
 // second halves.  On return with *found the allocator sits right behind a candidate that lies in another zone.
 void find_other_zone(int device, size_t budget, size_t skip, std::vector<Range>& held, pgx_buffers_info& info, bool* found) {
     *found = false;
+    hipStream_t st = probe_stream(device);
     held.emplace_back();
     if (make_chunk(device, PROBE_HALF, held.back()) != hipSuccess) { held.pop_back(); return; }
     void* ref = held.back().va;
     held.emplace_back();
     if (make_chunk(device, PROBE_HALF, held.back()) != hipSuccess) { held.pop_back(); return; }
     float t_same = 0.f;
-    if (probe_us(ref, held.back().va, PROBE_HALF, &t_same) != hipSuccess) return;
+    if (probe_us(st, ref, held.back().va, PROBE_HALF, &t_same) != hipSuccess) return;
     info.same_zone_us = info.final_us = t_same;
     // A one-zone stream sustains 5.4-6.2 TB/s on the devices measured, a 1:1 two-zone stream 6.7-7.0 TB/s: a pair that
     // already reaches 6.6 TB/s straddles a zone boundary as it is -- the allocator stands in the other zone already.
@@ -249,11 +320,11 @@ void find_other_zone(int device, size_t budget, size_t skip, std::vector<Range>&
                 (void)hipEventCreate(&b);
                 void* hi = held.back().va ? held.back().va : held[1].va;
                 for (int i = 0; i < 2; ++i)
-                    hipLaunchKernelGGL(pgx::zone_read_kernel, dim3(nblk), dim3(64), 0, 0, (const pgx::f32x4*)ref, (const pgx::f32x4*)hi, per_block, nblk, sink);
-                (void)hipEventRecord(a, 0);
+                    hipLaunchKernelGGL(pgx::zone_read_kernel, dim3(nblk), dim3(64), 0, st, (const pgx::f32x4*)ref, (const pgx::f32x4*)hi, per_block, nblk, sink);
+                (void)hipEventRecord(a, st);
                 for (int i = 0; i < 6; ++i)
-                    hipLaunchKernelGGL(pgx::zone_read_kernel, dim3(nblk), dim3(64), 0, 0, (const pgx::f32x4*)ref, (const pgx::f32x4*)hi, per_block, nblk, sink);
-                (void)hipEventRecord(b, 0);
+                    hipLaunchKernelGGL(pgx::zone_read_kernel, dim3(nblk), dim3(64), 0, st, (const pgx::f32x4*)ref, (const pgx::f32x4*)hi, per_block, nblk, sink);
+                (void)hipEventRecord(b, st);
                 (void)hipEventSynchronize(b);
                 float ms = 0.f;
                 (void)hipEventElapsedTime(&ms, a, b);
@@ -283,7 +354,7 @@ void find_other_zone(int device, size_t budget, size_t skip, std::vector<Range>&
         held.emplace_back();
         if (make_chunk(device, PROBE_HALF, held.back()) != hipSuccess) { held.pop_back(); (void)hipGetLastError(); break; }
         float t = 0.f;
-        if (probe_us(ref, held.back().va, PROBE_HALF, &t) != hipSuccess) break;
+        if (probe_us(st, ref, held.back().va, PROBE_HALF, &t) != hipSuccess) break;
         info.candidates += 1;
         if (getenv("PGX_DEBUG")) fprintf(stderr, "[pgx_buffers] %4.0f GiB of spacers: candidate %.1f us (same-zone pair %.1f us)\n", (double)spacer_bytes / (double)GiB, t, t_same);
         // Two kinds of other zone were seen (profiles/r2/placement_walk_scan.txt): one pairs with the reference at
@@ -318,7 +389,7 @@ void find_other_zone(int device, size_t budget, size_t skip, std::vector<Range>&
             fprintf(stderr, "[pgx_buffers]   %3zu:", i);
             for (size_t j = 0; j < c.size(); j += 3) {
                 float t = 0.f;
-                if (j <= i || probe_us(c[i], c[j], PROBE_HALF, &t) != hipSuccess) fprintf(stderr, "     .");
+                if (j <= i || probe_us(st, c[i], c[j], PROBE_HALF, &t) != hipSuccess) fprintf(stderr, "     .");
                 else fprintf(stderr, " %5.0f", t);
             }
             fprintf(stderr, "\n");
@@ -342,7 +413,10 @@ int pgx_buffers_create_at(int device, size_t bytes, int count, double skip_gib, 
     if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(device) != hipSuccess)
         return pgx::fail_msg(PGX_E_HIP, "cannot select HIP device %d", device);
     pgx_buffers* p = new (std::nothrow) pgx_buffers();
-    if (!p) return pgx::fail_msg(PGX_E_NOMEM, "out of host memory");
+    if (!p) {
+        (void)hipSetDevice(prev);
+        return pgx::fail_msg(PGX_E_NOMEM, "out of host memory");
+    }
     p->device = device;
     p->bytes = bytes;
     p->count = count;
@@ -406,7 +480,7 @@ int pgx_buffers_create_at(int device, size_t bytes, int count, double skip_gib, 
         double worst = 0.0;
         for (int i = 0; i < count; ++i) {
             float t = 0.f;
-            if (probe_us(p->va_of(i), (char*)p->va_of(i) + p->first, p->second, &t) != hipSuccess || t <= 0.f) continue;
+            if (probe_us(probe_stream(device), p->va_of(i), (char*)p->va_of(i) + p->first, p->second, &t) != hipSuccess || t <= 0.f) continue;
             const double gbs = 2.0 * (double)p->second / ((double)t * 1e-6) / 1e9;
             if (worst == 0.0 || gbs < worst) worst = gbs;
         }
@@ -441,6 +515,11 @@ int pgx_buffers_get_info(pgx_buffers* p, pgx_buffers_info* info) {
     if (!p || !info) return pgx::fail_msg(PGX_E_INVALID, "pgx_buffers_get_info: null argument");
     *info = p->info;
     return PGX_OK;
+}
+
+int64_t pgx_buffers_va_reserved(void) {
+    std::lock_guard<std::mutex> lock(g_va_mu);
+    return (int64_t)g_va_reserved;
 }
 
 int pgx_buffers_destroy(pgx_buffers* p) {

@@ -67,6 +67,7 @@ struct StepParams {
     int32_t obs_u8;    // 1: `obs` is uint8 (one byte per cell) instead of float32
     int32_t stagger;   // cohort stagger of the single-wave kernel (StepGeometry::stagger)
     int32_t store_policy;  // observation stores: 0 plain, 1 nontemporal, 2 sc1 write-through (StepGeometry::store_policy)
+    int32_t state_stores;  // when the small per-step result stores are issued: 0 at once, 1 after the LDS barrier, 2 after the stream
     int32_t soft_rule;    // PGX_SOFT_*  (docs/SPEC.md Q1)
     int32_t coop_reward;  // PGX_COOP_REWARD_* (Q4)
     int32_t bad_action;   // PGX_BAD_ACTION_* (Q7)
@@ -128,8 +129,9 @@ struct StepGeometry {
     bool p16;         // window side <= 16: packed 16-bit row masks aliased over the LDS state
     int stagger;      // > 0: odd wave slots sleep this many x 8128 cycles after issuing their loads
     int store_policy; // observation store flavour (pgx_kernels.hip: store_obs16)
+    int state_stores; // when the per-step result stores are issued (pgx_kernels.hip: emit_state)
     size_t lds_bytes;
-    // shares of the launch's workgroups per XCD (xcd_partition; equal until pgx_tune_xcd_shares or PGX_XCD_WEIGHTS)
+    // shares of the launch's workgroups per XCD (xcd_partition; equal until pgx_xcd_tune or PGX_XCD_WEIGHTS)
     int grid;             // workgroups to launch: 8 * the largest share
     int32_t xcd_n[8], xcd_base[8];
 };

@@ -287,8 +287,11 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
     // configs[4] step (523 -> 465 us), -2 % on configs[2], neutral on short launches (buffer-controlled A/B,
     // profiles/r1/controlled_ab.txt).  PGX_FLAGS bit 3 switches back to the identity mapping for A/B.
     // The XCDs do not get through their streams equally fast (the odd ones lag 5-15 %, whatever they write to:
-    // profiles/r2/xcd_rates.txt), so the shares need not be equal (pgx_tune_xcd_shares): workgroup b is the (b >> 3)-th
+    // profiles/r2/xcd_rates.txt), so the shares need not be equal (pgx_xcd_tune): workgroup b is the (b >> 3)-th
     // of XCD b & 7 and takes slice xcd_base + (b >> 3) if that XCD still has one.
+    // ASSUMPTION: blockIdx & 7 is the XCD -- true in SPX mode with 8 XCDs (round-robin dispatch of consecutive
+    // workgroups), which is how this pool's MI355X run.  In a partitioned mode (CPX/DPX ...) the mapping still covers
+    // every slice exactly once (results are unaffected); only the contiguity-per-L2 and the tuned shares lose their meaning.
     int blk = blockIdx.x;
     if (!(p.flags & 8u)) {
         // PGX_FLAGS bits 10..12 (diagnostic): XCD x takes the share of XCD (x + rot) & 7 -- does a slow XCD stay slow?
@@ -397,6 +400,67 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
     if (dbg2 && tid == 0) p.dbg[(size_t)blk * 4 + 1] = wall_clock64();
 
     // ---- phase 2: state update ---------------------------------------------------------------------
+    // The per-step results leave the wave through emit_state(): ~10 small global stores (rewards, flags, agent state,
+    // counters, metrics).  Under a saturated write stream a store INSTRUCTION can wait microseconds for a slot in the
+    // CU's memory pipeline (profiles/r3/timeline_short_cfg3.txt: "collisions resolved" p90 8 us, "state phase done" p90
+    // 25 us), so WHEN they are issued matters (StepParams::state_stores): 0 right after they are known, 1 after the
+    // cells have been published to LDS and the barrier has been passed (helper waves no longer wait for them),
+    // 2 after the wave's own observation stream (nobody waits for them at all).
+    struct StateOut {
+        float rew = 0.0f;
+        uint8_t term = 0;
+        bool trunc = false, finished = false, do_reset = false, act = false;
+        int n_arrived = 0;
+    } so;
+    const int when_stores = p.mode == MODE_STEP ? p.state_stores : 0;
+    const bool late_stores = when_stores != 0;
+    auto emit_state = [&](uint32_t pos_, uint32_t tgt_, bool active_, int elapsed_, int4 macc_, const StateOut& o) {
+        const bool fin = p.on_target == ON_TARGET_FINISH, coop = p.on_target == ON_TARGET_NOTHING;
+        if (valid) {
+            const size_t go = ROLL ? gi + (size_t)t * (size_t)rp.agents_stride : gi;
+            p.rewards[go] = o.rew;
+            p.terminated[go] = o.term;
+            p.truncated[go] = o.trunc ? 1 : 0;
+            if (p.act_out) p.act_out[go] = o.act ? 1 : 0;
+            if (o.do_reset && p.np_state) p.np_state[gi] = p.np_state0[gi];  // upstream re-creates the generators in reset()
+            p.pos[gi] = pos_;
+            p.tgt[gi] = tgt_;
+            p.active[gi] = active_ ? 1 : 0;
+        }
+        if (env_leader) {
+            p.elapsed[env] = o.do_reset ? 0 : elapsed_;
+            // ---- metric wrappers, fused: per-env accumulators, emitted when the episode finishes ----
+            const int n_arrived = o.n_arrived;
+            const int step = elapsed_ - 1;
+            if (fin) {
+                macc_.x += n_arrived;
+                macc_.y += n_arrived * step;
+                if (n_arrived) macc_.z = max(macc_.z, step);
+            } else if (p.on_target == ON_TARGET_RESTART) {
+                macc_.w += n_arrived;
+            }
+            if (o.finished && p.metrics_out) {
+                float* mo = p.metrics_out + ((size_t)env + (ROLL ? (size_t)t * (size_t)rp.envs_stride : 0)) * 6;
+                const float fA = (float)A;
+                if (fin) {
+                    const int unsolved = A - macc_.x;
+                    const int total = macc_.y + unsolved * step;
+                    const int mx = unsolved ? step : macc_.z;
+                    mo[0] = (float)macc_.x / fA; mo[1] = macc_.x == A ? 1.0f : 0.0f; mo[2] = (float)total / fA + 1.0f;
+                    mo[3] = (float)(total + A); mo[4] = (float)(mx + 1); mo[5] = 0.0f;
+                } else if (coop) {
+                    mo[0] = (float)n_arrived / fA; mo[1] = n_arrived == A ? 1.0f : 0.0f; mo[2] = (float)(step + 1);
+                    mo[3] = (float)(A * (step + 1)); mo[4] = (float)(step + 1); mo[5] = 0.0f;
+                } else {
+                    const int denom = p.max_steps > 0 ? p.max_steps : step + 1;
+                    mo[0] = 0.0f; mo[1] = 0.0f; mo[2] = (float)(step + 1); mo[3] = 0.0f; mo[4] = 0.0f;
+                    mo[5] = (float)macc_.w / (float)denom;
+                }
+            }
+            if (p.episode_done) p.episode_done[(size_t)env + (ROLL ? (size_t)t * (size_t)rp.envs_stride : 0)] = o.finished ? 1 : 0;
+            p.macc[env] = o.finished ? make_int4(0, 0, 0, 0) : macc_;
+        }
+    };
     {
         const uint32_t* obm = s_obst + env_l * bmw;
         if (act < 0 || act > 4) {  // docs/SPEC.md Q7: a noop either way; FLAG also counts it for the host's IndexError
@@ -507,7 +571,6 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
             // ================= goals, rewards, done flags ==========
             const bool on_goal = valid && pos == tgt;
             const bool arrived = on_goal && active;  // `was_on_goal` of the reference
-            int n_arrived;
             bool solved, all_on_goal;
             if (MW && !solo) {
                 const unsigned long long ma = __ballot(arrived);
@@ -519,20 +582,20 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
                     if (mo) s_misc[MISC_OFFGOAL] = 1u;
                 }
                 lds_sync<true>();
-                n_arrived = (int)s_misc[MISC_ARRIVED];
+                so.n_arrived = (int)s_misc[MISC_ARRIVED];
                 solved = s_misc[MISC_UNSOLVED] == 0u;
                 all_on_goal = s_misc[MISC_OFFGOAL] == 0u;
             } else {
                 const unsigned long long ma = __ballot(arrived);
-                if constexpr (G == 64) n_arrived = __popcll(ma);
-                else n_arrived = __popcll((ma >> gbase) & ((1ull << G) - 1ull));
+                if constexpr (G == 64) so.n_arrived = __popcll(ma);
+                else so.n_arrived = __popcll((ma >> gbase) & ((1ull << G) - 1ull));
                 solved = !group_any<G>(valid && !arrived, gbase);
                 all_on_goal = !group_any<G>(valid && !on_goal, gbase);
             }
             const bool coop = p.on_target == ON_TARGET_NOTHING;
             const bool fin = p.on_target == ON_TARGET_FINISH;
-            const float rew = ((coop && p.coop_reward == 0) ? solved : arrived) ? 1.0f : 0.0f;  // Q4
-            const uint8_t term = (coop ? solved : (fin && on_goal)) ? 1 : 0;
+            so.rew = ((coop && p.coop_reward == 0) ? solved : arrived) ? 1.0f : 0.0f;  // Q4
+            so.term = (coop ? solved : (fin && on_goal)) ? 1 : 0;
             const bool all_term = coop ? solved : (fin && all_on_goal);
             if (fin && on_goal) {  // hide_agent
                 active = false;
@@ -557,58 +620,17 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
                 p.tcount[gi] = cnt + 1;
             }
             elapsed += 1;
-            const bool trunc = p.max_steps > 0 && elapsed >= p.max_steps;
-            const bool do_reset = p.auto_reset && (all_term || trunc);
-            if (valid) {
-                const size_t go = ROLL ? gi + (size_t)t * (size_t)rp.agents_stride : gi;
-                p.rewards[go] = rew;
-                p.terminated[go] = term;
-                p.truncated[go] = trunc ? 1 : 0;
-                if (p.act_out) p.act_out[go] = active ? 1 : 0;
-                if (do_reset) {  // auto-reset wrapper: observation comes from the reset state
-                    pos = p.pos0[gi];
-                    tgt = p.tgt0[gi];
-                    active = true;
-                    vis = to_c22(pos);
-                    if (p.np_state) p.np_state[gi] = p.np_state0[gi];  // upstream re-creates the generators in reset()
-                }
-                p.pos[gi] = pos;
-                p.tgt[gi] = tgt;
-                p.active[gi] = active ? 1 : 0;
+            so.trunc = p.max_steps > 0 && elapsed >= p.max_steps;
+            so.finished = all_term || so.trunc;
+            so.do_reset = p.auto_reset && so.finished;
+            so.act = active;  // is_active as reported for THIS step (before an auto-reset re-activates everybody)
+            if (valid && so.do_reset) {  // auto-reset wrapper: observation comes from the reset state
+                pos = p.pos0[gi];
+                tgt = p.tgt0[gi];
+                active = true;
+                vis = to_c22(pos);
             }
-            if (env_leader) {
-                p.elapsed[env] = do_reset ? 0 : elapsed;
-                // ---- metric wrappers, fused: per-env accumulators, emitted when the episode finishes ----
-                const bool finished = all_term || trunc;
-                const int step = elapsed - 1;
-                if (fin) {
-                    macc.x += n_arrived;
-                    macc.y += n_arrived * step;
-                    if (n_arrived) macc.z = max(macc.z, step);
-                } else if (p.on_target == ON_TARGET_RESTART) {
-                    macc.w += n_arrived;
-                }
-                if (finished && p.metrics_out) {
-                    float* mo = p.metrics_out + ((size_t)env + (ROLL ? (size_t)t * (size_t)rp.envs_stride : 0)) * 6;
-                    const float fA = (float)A;
-                    if (fin) {
-                        const int unsolved = A - macc.x;
-                        const int total = macc.y + unsolved * step;
-                        const int mx = unsolved ? step : macc.z;
-                        mo[0] = (float)macc.x / fA; mo[1] = macc.x == A ? 1.0f : 0.0f; mo[2] = (float)total / fA + 1.0f;
-                        mo[3] = (float)(total + A); mo[4] = (float)(mx + 1); mo[5] = 0.0f;
-                    } else if (coop) {
-                        mo[0] = (float)n_arrived / fA; mo[1] = n_arrived == A ? 1.0f : 0.0f; mo[2] = (float)(step + 1);
-                        mo[3] = (float)(A * (step + 1)); mo[4] = (float)(step + 1); mo[5] = 0.0f;
-                    } else {
-                        const int denom = p.max_steps > 0 ? p.max_steps : step + 1;
-                        mo[0] = 0.0f; mo[1] = 0.0f; mo[2] = (float)(step + 1); mo[3] = 0.0f; mo[4] = 0.0f;
-                        mo[5] = (float)macc.w / (float)denom;
-                    }
-                }
-                if (p.episode_done) p.episode_done[(size_t)env + (ROLL ? (size_t)t * (size_t)rp.envs_stride : 0)] = finished ? 1 : 0;
-                p.macc[env] = finished ? make_int4(0, 0, 0, 0) : macc;
-            }
+            if (!late_stores) emit_state(pos, tgt, active, elapsed, macc, so);
         }
 
         // ---- publish agent cells to LDS and rebuild the occupancy bitmap ------------------------
@@ -623,8 +645,12 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
         }
     }
     if (dbg && tid == 0) p.dbg[(size_t)blk * 4 + (dbg2 ? 3 : 1)] = wall_clock64();
-    if (!p.obs) return;
+    if (!p.obs) {
+        if (late_stores) emit_state(pos, tgt, active, elapsed, macc, so);
+        return;
+    }
     lds_sync<MW>();
+    if (when_stores == 1) emit_state(pos, tgt, active, elapsed, macc, so);
     float* const obs_out = ROLL ? reinterpret_cast<float*>(reinterpret_cast<char*>(p.obs) + (size_t)slot * (size_t)rp.obs_stride) : p.obs;
 
     if constexpr (P16) {
@@ -693,6 +719,7 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
             stream_obs_u8(reinterpret_cast<uint8_t*>(obs_out), base, n, W, p.w_magic, tid, NT, p.store_policy == 1,
                           [&](int row) -> uint32_t { return row < nrows ? (uint32_t)rows16[row] : 0u; }, wave,
                           (MW && !(p.flags & 512u)) ? nw : 1);
+            if (when_stores == 2) emit_state(pos, tgt, active, elapsed, macc, so);
             if (dbg && !dbg2 && tid == 0) {
                 __builtin_amdgcn_s_waitcnt(0);
                 p.dbg[(size_t)blk * 4 + 3] = wall_clock64();
@@ -722,7 +749,8 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
         // Multi-wave workgroups: every wave streams its own CONTIGUOUS part of the slice, 1 KiB per store instruction,
         // like the single-wave kernel.  Interleaving the waves (q = tid, q += NT) makes each wave hop by NT * 16 bytes:
         // with 4 waves that is 4 KiB, with 8 waves 8 KiB -- every store of a wave then lands on the same memory channel
-        // (configs[2] forced onto 3 / 4 / 8 waves: 120 / 147 / 419 us per step, profiles/r2/wave_span_ab.txt).
+        // (configs[2] forced onto 3 / 4 / 8 waves with the interleaved order: 120 / 147 / 419 us per step, measured in
+        // round 2 with tools/ab_inproc.py; the raw output was not kept -- PGX_WAVES=k with PGX_FLAGS=512 reproduces it).
         // PGX_FLAGS bit 9 restores the interleaved order for A/B.
         const bool span = MW && !(p.flags & 512u);
         const int part = (nvec + nw - 1) / nw;
@@ -749,6 +777,7 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
                 row += 1;
             }
         }
+        if (when_stores == 2) emit_state(pos, tgt, active, elapsed, macc, so);
         if (dbg && !dbg2 && tid == 0) {
             __builtin_amdgcn_s_waitcnt(0);
             p.dbg[(size_t)blk * 4 + 3] = wall_clock64();
@@ -797,6 +826,7 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
         stream_obs_u8(reinterpret_cast<uint8_t*>(obs_out), (size_t)env0 * A * 3 * W * W, nrows * W, W, p.w_magic, tid, NT,
                       p.store_policy == 1, [&](int row) -> uint32_t { return row < nrows ? s_rows[row] : 0u; }, wave,
                       (MW && !(p.flags & 512u)) ? nw : 1);
+        if (when_stores == 2) emit_state(pos, tgt, active, elapsed, macc, so);
         return;
     }
     {
@@ -836,6 +866,7 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
             v.w = (float)((b >> 3) & 1u);
             store_obs16(reinterpret_cast<f32x4_t*>(&out4[q]), v, (uint32_t)p.store_policy);
         }
+        if (when_stores == 2) emit_state(pos, tgt, active, elapsed, macc, so);
         if (dbg && !dbg2 && tid == 0) {
             __builtin_amdgcn_s_waitcnt(0);  // stores retired (vmcnt 0) before the end stamp
             p.dbg[(size_t)blk * 4 + 3] = wall_clock64();
@@ -1063,6 +1094,10 @@ StepGeometry step_geometry(int batch, int A, int bmw, int W, bool allow_p16, int
     }
     g.p16 = allow_p16 && W <= 16;
     g.store_policy = g.multi_wave ? 1 : 2;  // see store_obs16()
+    // The small per-step result stores go out after the LDS barrier (emit_state(), mode 1): in-process A/B on shared
+    // buffers (profiles/r3/state_stores_ab.txt) configs[3] 39.9 -> 39.1 us, configs[2] 115.7 -> 115.1, configs[1]/[4]
+    // unchanged; after the stream (mode 2) configs[3] 39.3, configs[2] 116.5.  PGX_STATE_STORES overrides.
+    g.state_stores = 1;
     // Cohort stagger (step_kernel phase 1): pays when every wave of the launch is resident at once (one round of at
     // most 256 CUs x 32 waves, at least half of them used) and each wave streams for long (>= 32 KB of observations):
     // -2.3 % per configs[2] step in a buffer-controlled A/B on two boxes (profiles/r1/controlled_ab.txt); with several

@@ -128,8 +128,23 @@ class Pogema:
         self._vec.load_state(self._history.pop())
         return True
 
+    def _refuse_bad_actions(self, action):
+        """Semantics(bad_action='flag'): the reference indexes MOVES[action] for every ACTIVE agent before anything
+        moves, so an out-of-range action raises IndexError with the state untouched.  The actions of this API are host
+        values: check them here, BEFORE the engine steps (the is_active flags are fetched only when something is out
+        of range).  Python's negative wrap-around (MOVES[-1]) is not reproduced: negative actions are refused."""
+        acts = np.asarray(action).reshape(-1)
+        out_of_range = (acts < 0) | (acts >= len(self.grid_config.MOVES))
+        if out_of_range.any():
+            active = self._vec.get_state()["is_active"][0].cpu().numpy().astype(bool)
+            bad = int((out_of_range & active).sum())
+            if bad:
+                raise IndexError(f"{bad} action(s) of active agents were outside 0..{len(self.grid_config.MOVES) - 1}")
+
     def step(self, action):
         assert len(action) == self.get_num_agents()
+        if self._vec.semantics.bad_action == "flag":
+            self._refuse_bad_actions(action)
         if self._history is not None:
             self._history.append(self._vec.save_state())
         import torch
@@ -147,7 +162,9 @@ class Pogema:
         torch.cuda.current_stream(vec.device).synchronize()
         if vec.semantics.bad_action == "flag":  # the reference's IndexError on MOVES[action]
             bad = int(vec._lib.pgx_bad_action_count(vec._handle, vec._stream()))
-            if bad:
+            if bad < 0:
+                _lib.check(bad)
+            if bad:  # unreachable after _refuse_bad_actions; kept as the engine's own verdict
                 raise IndexError(f"{bad} action(s) of active agents were outside 0..{len(self.grid_config.MOVES) - 1}")
         v = io["views"]
         obs = v["obs"].copy()

@@ -61,6 +61,14 @@ class PipelinedVecPogema:
                 out.append(e.reset(seed=seed))
         return out
 
+    def warm_buffers(self):
+        """`VecPogema.warm_buffers` of every part (zone walk and candidate timing outside the sampling loop)."""
+        out = []
+        for i, e in enumerate(self.engines):
+            with self.stream(i):
+                out.append(e.warm_buffers())
+        return out
+
     def step_part(self, i: int, actions, **kw):
         """`VecPogema.step` of part i, enqueued on part i's stream; `actions`: [batch / parts, agents].  If the actions
         were produced on another stream, make part i's stream wait for them first (`wait_for`)."""

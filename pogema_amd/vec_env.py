@@ -59,6 +59,10 @@ class VecPogema:
     where its output buffer lives).  ALIASING: with `reuse_buffers=True` every tensor returned by step t (obs, rewards,
     terminated, truncated, infos['is_active']) is overwritten by step t+2 -- consume or copy it before then, or hand
     step() your own buffers with `out=`.  `reuse_buffers="single"`: one set only, overwritten by EVERY step.
+    The buffers are picked on first use: a zone walk that holds up to `placement_budget_gib` of HBM for 1-2 s and
+    synchronises the device.  Call `warm_buffers()` after reset() to have that happen at a moment of your choosing
+    (required before capturing step() in a HIP graph); if the walk fails (another process took the memory meanwhile)
+    the buffers come from torch's allocator and `placement["fallback"]` says why.
 
     `semantics`: switches for the three low-confidence recollections of the reference (pogema_amd/semantics.py).
     Seeds: `reset(seed)` selects the instances (maps, starts, targets); the lifelong target stream and the
@@ -68,7 +72,7 @@ class VecPogema:
     def __init__(self, grid_config: Optional[GridConfig] = None, batch: int = 1, device="cuda:0",
                  env_index_base: int = 0, auto_reset: Optional[bool] = None, reuse_buffers: bool = False,
                  obs_dtype=torch.float32, semantics: Optional[Semantics] = None,
-                 placement_probe: Optional[bool] = None):
+                 placement_probe: Optional[bool] = None, placement_budget_gib=None):
         self.grid_config = grid_config if grid_config is not None else GridConfig(num_agents=2)
         gc = self.grid_config
         self.observation_type = gc.observation_type  # 'default' tensor, or 'POMAPF' / 'MAPF' dict views
@@ -112,6 +116,10 @@ class VecPogema:
         self.semantics = semantics if semantics is not None else Semantics.from_env()
         # placement probe of the double-buffered observation tensors (reuse_buffers=True); PGX_PLACEMENT=0 disables
         self.placement_probe = (os.environ.get("PGX_PLACEMENT") != "0") if placement_probe is None else bool(placement_probe)
+        # HBM the zone walk may hold for its ~1-2 s (buffers.ZoneBuffers): None = half of the free memory (safe on a
+        # device shared with other processes), "all" = everything but the engine's 10 % reserve (a process that owns
+        # the device: bench.py), a number = GiB, 0 = no walk
+        self.placement_budget_gib = placement_budget_gib
         # float32 is the reference's observation dtype (gymnasium Box float32) and the default; torch.uint8 writes
         # the same 0/1 planes one byte per cell (4x fewer HBM bytes per step) for callers that cast on their side
         if obs_dtype not in _lib.OBS_DTYPES:
@@ -389,18 +397,16 @@ class VecPogema:
         obs_bytes = int(np.prod(self.obs_shape)) * (4 if self.obs_dtype == torch.float32 else 1)
         n = 1 if self.single_buffer else 2
         if not self.placement_probe or obs_bytes < self.PLACEMENT_MIN_BYTES:
-            self.placement = {"spread": False, "method": "torch allocator"}
-            bufs = [torch.empty(self.obs_shape, dtype=self.obs_dtype, device=self.device) for _ in range(n)]
-            if self.placement_probe and self.batch >= 2048:
-                self.placement.update(self.tune_xcd_shares(bufs[0], bufs[-1] if n > 1 else None))
-            return bufs
-        from .buffers import ZoneBuffers
+            return self._plain_obs_buffers(n)
         # The walk's verdict does not always carry over to the real buffers (halves may straddle a boundary), and some
         # boxes show no zones at all: ask the pool for two buffers more than needed, time the observation stream itself
         # into each of them and into a few buffers as torch's allocator hands them out, keep the fastest n and give
         # the rest back.
         spare = self.SPARE_BUFFERS if self._has_state() else 0
-        pools = [ZoneBuffers(self.obs_shape, self.obs_dtype, self.device, count=n + spare)]
+        try:
+            pools = [self._zone_pool(n + spare)]
+        except _lib.PgxError as e:  # e.g. a concurrent allocation took the memory during the walk: plain buffers
+            return self._plain_obs_buffers(n, fallback=str(e))
         # candidates: (observation pass [us], order, kind, tensor, pool index, index inside the pool)
         cands = [(self._time_observe(t), i, "zone", t, 0, i) for i, t in enumerate(pools[0].tensors)]
         # The probe's promise, scaled to this tensor: if the n-th best buffer misses it by 10 % the fast stretch was
@@ -411,8 +417,10 @@ class VecPogema:
             nth = sorted(c[0] for c in cands)[n - 1]
             if not info["spread"] or info["final_us"] <= 0 or nth <= retry * info["final_us"] * obs_bytes / (2 * (384 << 20)):
                 break
-            pools.append(ZoneBuffers(self.obs_shape, self.obs_dtype, self.device, count=n + spare,
-                                     skip_gib=info["spacer_gib"] + 16.0))
+            try:
+                pools.append(self._zone_pool(n + spare, skip_gib=info["spacer_gib"] + 16.0))
+            except _lib.PgxError:
+                break  # keep what the first pool gave
             k = len(pools) - 1
             cands += [(self._time_observe(t), len(cands) + i, "zone", t, k, i) for i, t in enumerate(pools[k].tensors)]
         self.placement = dict(pools[0].info, method="pgx_buffers (two HBM zones per buffer)", pools_tried=len(pools))
@@ -451,6 +459,33 @@ class VecPogema:
         torch.cuda.empty_cache()
         return result
 
+    def _zone_pool(self, count: int, skip_gib: float = 0.0):
+        from .buffers import ZoneBuffers
+        return ZoneBuffers(self.obs_shape, self.obs_dtype, self.device, count=count,
+                           max_spacer_gib=self.placement_budget_gib, skip_gib=skip_gib)
+
+    def _plain_obs_buffers(self, n: int, fallback: Optional[str] = None):
+        """Observation buffers as torch's allocator hands them out (small tensors, probe switched off, failed walk)."""
+        self.placement = {"spread": False, "method": "torch allocator"}
+        if fallback is not None:
+            self.placement["fallback"] = fallback
+            torch.cuda.empty_cache()
+        bufs = [torch.empty(self.obs_shape, dtype=self.obs_dtype, device=self.device) for _ in range(n)]
+        if self.placement_probe and self.batch >= 2048:
+            self.placement.update(self.tune_xcd_shares(bufs[0], bufs[-1] if n > 1 else None))
+        return bufs
+
+    def warm_buffers(self) -> dict:
+        """Pick the reused output buffers NOW (reuse_buffers=True / "single"; a no-op otherwise or when already done):
+        zone walk, timing of the candidates, XCD share tuning -- 1-3 s during which up to `placement_budget_gib` of HBM
+        is held and the device is synchronised.  Without this call the first step() does it.  Needs an installed state
+        (reset() first) to time the real observation stream; returns `placement`."""
+        if self.reuse_buffers and self._bufs is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("warm_buffers() synchronises the device: call it before the graph capture starts")
+            self._bufs = [(obs,) + self._alloc_outputs(False)[1:] for obs in self._pick_obs_buffers()]
+        return self.placement or {}
+
     def tune_xcd_shares(self, obs: torch.Tensor, obs_alt: Optional[torch.Tensor] = None, rounds: int = 6) -> dict:
         """pgx_xcd_tune: shift work between the 8 XCDs until they finish a launch together (the odd XCDs get through
         their streams 5-15 % slower); keeps the shares with the shortest observation pass, equal shares included."""
@@ -485,7 +520,10 @@ class VecPogema:
         if not self.reuse_buffers:
             return self._alloc_outputs()
         if self._bufs is None:
-            self._bufs = [(obs,) + self._alloc_outputs(False)[1:] for obs in self._pick_obs_buffers()]
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("reuse_buffers: the output buffers are picked by a timed zone walk that synchronises "
+                                   "the device -- call warm_buffers() (or one un-captured step) before capturing")
+            self.warm_buffers()
         self._buf_i = 0 if self.single_buffer else self._buf_i ^ 1
         return self._bufs[self._buf_i]
 
@@ -531,7 +569,13 @@ class VecPogema:
         Output buffers: fresh tensors per call by default; with `reuse_buffers=True` two alternating sets, so whatever
         step t returned is OVERWRITTEN BY STEP t+2 (consume or copy it before); with
         `out=(obs, rewards, terminated, truncated, is_active)` the caller's own tensors are written (bool or uint8
-        flags; `obs` may be None together with compute_obs=False) and returned."""
+        flags; `obs` may be None together with compute_obs=False) and returned.
+
+        Semantics(bad_action="flag"): the actions live on the device, so an out-of-range action of an active agent is
+        detected BY the step -- the IndexError is raised after the launch (one host sync per step), the step has been
+        applied with that agent standing still, and the output buffers of this call have been written.  The reference
+        raises before any state change; callers who need that take `save_state()` before a step they do not trust, or
+        use the list API (`pogema_v0`), whose host-side actions are checked before the engine is called."""
         actions = self._prepare_actions(actions)
         if out is not None:
             obs, rewards, terminated, truncated, is_active = self._check_out(out)
@@ -609,11 +653,15 @@ class VecPogema:
                 if entry is None:
                     # two buffers more than needed; the run of `slots` consecutive ones into which the observation
                     # stream itself is fastest becomes the ring, the others are given back (see _pick_obs_buffers)
-                    from .buffers import ZoneBuffers
                     retry = float(os.environ.get("PGX_POOL_RETRY", "1.10"))
                     pool, times, start, skip = None, None, 0, 0.0
                     for _ in range(3):  # as in _pick_obs_buffers: try further on while the ring misses the probe's promise
-                        cand = ZoneBuffers(self.obs_shape, self.obs_dtype, dev, count=slots + 2, skip_gib=skip)
+                        try:
+                            cand = self._zone_pool(slots + 2, skip_gib=skip)
+                        except _lib.PgxError as e:  # failed walk (memory taken meanwhile): keep an earlier pool, if any
+                            if pool is None:
+                                self.placement = {"spread": False, "method": "torch allocator", "fallback": str(e)}
+                            break
                         ct = [self._time_observe(t) for t in cand.tensors]
                         cs = min(range(3), key=lambda s: (max(ct[s:s + slots]), s))
                         if pool is None or max(ct[cs:cs + slots]) < max(times[start:start + slots]):
@@ -624,18 +672,20 @@ class VecPogema:
                                 max(times[start:start + slots]) <= retry * info["final_us"] * obs_bytes / (2 * (384 << 20))):
                             break
                         skip = info["spacer_gib"] + 16.0
-                    ring = pool.ring_view(start, slots)
-                    for i in range(slots + 2):
-                        if not start <= i < start + slots:
-                            pool.drop(i)
-                    entry = self._rollout_pools[slots] = (pool, ring)
-                    self.placement = dict(pool.info, method="pgx_buffers (two HBM zones per buffer)",
-                                          observe_us=[round(t, 1) for t in times[start:start + slots]],
-                                          observe_us_zone=[round(t, 1) for t in times])
-                    if "xcd_shares" not in self.placement and self._bufs is None:
-                        self.placement.update(self.tune_xcd_shares(ring[0], ring[1] if slots > 1 else None))
-                obs, slot_stride = entry[1], entry[0].stride_bytes
-            else:
+                    if pool is not None:
+                        ring = pool.ring_view(start, slots)
+                        for i in range(slots + 2):
+                            if not start <= i < start + slots:
+                                pool.drop(i)
+                        entry = self._rollout_pools[slots] = (pool, ring)
+                        self.placement = dict(pool.info, method="pgx_buffers (two HBM zones per buffer)",
+                                              observe_us=[round(t, 1) for t in times[start:start + slots]],
+                                              observe_us_zone=[round(t, 1) for t in times])
+                        if "xcd_shares" not in self.placement and self._bufs is None:
+                            self.placement.update(self.tune_xcd_shares(ring[0], ring[1] if slots > 1 else None))
+                if entry is not None:
+                    obs, slot_stride = entry[1], entry[0].stride_bytes
+            if obs is None:
                 obs = torch.empty((slots,) + self.obs_shape, dtype=self.obs_dtype, device=dev)
         out = {
             "obs": obs,

@@ -62,3 +62,87 @@ def test_engine_parity_on_zone_buffers():
     assert envs[1].placement["method"].startswith("pgx_buffers")
     for e in envs:
         e.close()
+
+
+def test_failed_walk_falls_back_to_plain_buffers(monkeypatch):
+    """a zone walk that fails (another process took the memory meanwhile -> PGX_E_NOMEM) must not surface
+    as an error of step(): the buffers then come from torch's allocator and `placement` says why."""
+    import torch
+    from pogema_amd import GridConfig, VecPogema, _lib
+    gc = GridConfig(size=16, num_agents=8, obs_radius=3, density=0.2, seed=1)
+    env = VecPogema(gc, batch=64, auto_reset=True, reuse_buffers=True)
+    env.PLACEMENT_MIN_BYTES = 1  # force the pool path for this small tensor
+    calls = []
+
+    def boom(count, skip_gib=0.0):
+        calls.append(count)
+        raise _lib.PgxError(-3, "hipMemCreate/hipMemMap (second half): out of memory")
+
+    monkeypatch.setattr(env, "_zone_pool", boom)
+    env.reset(seed=1)
+    acts = torch.randint(0, 5, (64, 8), device="cuda", dtype=torch.int8)
+    obs, *_ = env.step(acts)
+    assert calls and env.placement["method"] == "torch allocator" and "out of memory" in env.placement["fallback"]
+    assert obs.shape == env.obs_shape and not env.placement["spread"]
+    out = env.rollout(steps=3, obs_slots=2)  # the rollout ring takes the same fallback
+    assert out["obs"].shape[0] == 2 and out["obs"].is_contiguous()
+    env.close()
+
+
+def test_warm_buffers_is_explicit_and_capture_is_guarded():
+    """warm_buffers() picks the output buffers at a moment of the caller's choosing; an un-warmed first step inside a
+    graph capture is refused with a clear message instead of synchronising inside the capture."""
+    import torch
+    from pogema_amd import GridConfig, VecPogema
+    gc = GridConfig(size=16, num_agents=8, obs_radius=3, density=0.2, seed=1)
+    acts = torch.randint(0, 5, (64, 8), device="cuda", dtype=torch.int8)
+    cold = VecPogema(gc, batch=64, auto_reset=True, reuse_buffers=True)
+    cold.reset(seed=1)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        g = torch.cuda.CUDAGraph()
+        with pytest.raises(RuntimeError, match="warm_buffers"):
+            with torch.cuda.graph(g, stream=s):
+                cold.step(acts)
+    torch.cuda.synchronize()
+    cold.close()
+    env = VecPogema(gc, batch=64, auto_reset=True, reuse_buffers=True)
+    env.reset(seed=1)
+    assert env._bufs is None
+    pl = env.warm_buffers()
+    assert env._bufs is not None and pl["method"] == "torch allocator"  # 0.3 MB: no walk for such a tensor
+    bufs = env._bufs
+    assert env.warm_buffers() is env.placement and env._bufs is bufs  # idempotent
+    ref = VecPogema(gc, batch=64, auto_reset=True)
+    ref.reset(seed=1)
+    with torch.cuda.stream(s):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            o1 = env.step(acts)[0]
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(o1, ref.step(acts)[0])
+    env.close(); ref.close()
+
+
+def test_address_space_accounting():
+    """Pools never give their address ranges back nor re-use them (ROCm 7.2 keeps stale translations either way:
+    profiles/r2/vmm_va_reuse_fault.txt, profiles/r3/vmm_va_remap_stale.txt), so every pool costs count x stride of
+    address space -- and nothing more: the probe chunks of the zone walk are plain hipMalloc memory."""
+    import torch
+    from pogema_amd import _lib
+    from pogema_amd.buffers import ZoneBuffers
+    lib = _lib.load()
+    ptrs = []
+    for shape, kw in (((5, 1 << 20), dict(max_spacer_gib=0)), ((5, 1 << 20), dict(max_spacer_gib=0)),
+                      ((3072, 64, 3, 11, 11), dict())):  # the last one walks (285 MB per buffer)
+        before = int(lib.pgx_buffers_va_reserved())
+        pool = ZoneBuffers(shape, torch.float32, "cuda:0", count=2, **kw)
+        assert int(lib.pgx_buffers_va_reserved()) - before == 2 * pool.stride_bytes
+        for i, t in enumerate(pool.tensors):
+            t.fill_(float(i + 1))
+        torch.cuda.synchronize()
+        assert all(bool((t == float(i + 1)).all()) for i, t in enumerate(pool.tensors))
+        ptrs.append(pool.tensors[0].data_ptr())
+        del pool, t
+    assert len(set(ptrs)) == 3, "a released range is not handed out again"

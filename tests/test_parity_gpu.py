@@ -270,6 +270,17 @@ def test_bad_actions_noop_and_flag():
         env.step(torch.from_numpy(bad[1]).cuda())
     env.step(torch.from_numpy(good[2]).cuda())  # the counter was cleared by the raise
     env.close()
+    # list API: the actions are host values and are refused BEFORE anything moves, as the reference's MOVES[action] does
+    from pogema_amd import pogema_v0
+    one = pogema_v0(GridConfig(map=obstacles[0].tolist(), agents_xy=agents[0].tolist(), targets_xy=targets[0].tolist(),
+                               num_agents=A, obs_radius=r, collision_system="soft"), semantics=Semantics(bad_action="flag"))
+    one.reset()
+    before = one.get_agents_xy()
+    with pytest.raises(IndexError):
+        one.step([1, 7, 0, 0, 0, 0])
+    assert one.get_agents_xy() == before, "an out-of-range action must leave the state untouched"
+    one.step([1, 2, 3, 4, 0, 0])  # in range: accepted
+    one.close()
 
 
 @pytest.mark.parametrize("geom", [g for g in GEOMETRIES if g[0] in ("baseline_cfg1", "dense_small", "full_wave", "two_slots")],

@@ -18,7 +18,7 @@ variants = sys.argv[2:]
 batch, size, agents, r = WL[wl]
 envs = []
 for v in variants:
-    for k in ("PGX_FLAGS", "PGX_EPW", "PGX_STAGGER", "PGX_LDS_MIN", "PGX_WAVES", "PGX_STORE", "PGX_TEAM"):
+    for k in ("PGX_FLAGS", "PGX_EPW", "PGX_STAGGER", "PGX_LDS_MIN", "PGX_WAVES", "PGX_STORE", "PGX_TEAM", "PGX_STATE_STORES"):
         os.environ.pop(k, None)
     for kv in v.split(","):
         if kv:
@@ -31,6 +31,8 @@ for v in variants:
     # 10 % (profiles/r1/placement_tiers.txt), which would otherwise drown the effect under test
     if envs:
         env._bufs = [(envs[0]._bufs[k][0],) + env._alloc_outputs(False)[1:] for k in range(2)]
+        if batch >= 2048:  # like the first variant: its own XCD shares, tuned on the shared buffers
+            env.tune_xcd_shares(env._bufs[0][0], env._bufs[1][0])
     else:
         env._outputs()
         print("buffers:", getattr(env, "placement", None))

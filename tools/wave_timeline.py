@@ -35,9 +35,16 @@ for name, col in (("start", 0), ("resolve done", 1), ("first store", 2), ("end",
 print("per-wave prologue (start->first store) p50 %.1f us, p90 %.1f us; store phase p50 %.1f us, p90 %.1f us" % (
     np.percentile(t[:, 2] - t[:, 0], 50), np.percentile(t[:, 2] - t[:, 0], 90),
     np.percentile(t[:, 3] - t[:, 2], 50), np.percentile(t[:, 3] - t[:, 2], 90)))
-edges = np.arange(0, t[:, 3].max() + 5, 5.0)
-print("time(us)  running  storing")
+# estimated write rate over time: every workgroup writes its slice at a uniform rate between its first store and the
+# acknowledgement of its last one
+wg_bytes = batch * agents * 3 * (2 * r + 1) ** 2 * 4 / len(buf)
+dur = np.maximum(t[:, 3] - t[:, 2], 0.01)
+step_us = float(os.environ.get("TL_STEP", "4"))
+edges = np.arange(0, t[:, 3].max() + step_us, step_us)
+print("time(us)  running  storing  est. TB/s over the next %.0f us" % step_us)
 for a in edges:
     running = int(((t[:, 0] <= a) & (t[:, 3] > a)).sum())
     storing = int(((t[:, 2] <= a) & (t[:, 3] > a)).sum())
-    print(f"{a:7.0f}  {running:7d}  {storing:7d}")
+    ov = np.clip(np.minimum(t[:, 3], a + step_us) - np.maximum(t[:, 2], a), 0, None)
+    rate = float((ov / dur * wg_bytes).sum()) / (step_us * 1e-6) / 1e12
+    print(f"{a:7.0f}  {running:7d}  {storing:7d}  {rate:6.2f}")

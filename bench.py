@@ -177,7 +177,7 @@ def launch_ranks(n: int, argv, stub: bool = False) -> int:
 class EngineStep:
     """The product path: VecPogema on this rank's device."""
 
-    def __init__(self, args, rank, device, batch, env_base, size, agents, r, placement_probe=True):
+    def __init__(self, args, rank, device, batch, env_base, size, agents, r, placement_probe=True, buffers=None):
         import torch
         from pogema_amd import GridConfig, VecPogema
         self.torch = torch
@@ -186,7 +186,9 @@ class EngineStep:
                         max_episode_steps=args.max_episode_steps)
         self.env = VecPogema(gc, batch=batch, device=device, env_index_base=env_base,
                              auto_reset=True if args.auto_reset == "restore" else "regenerate",
-                             reuse_buffers=True if args.buffers == 2 else "single",
+                             # (--graph: the captured steps need fixed buffers -> two alternating sets)
+                             reuse_buffers={0: True if args.graph > 0 else "recycle", 1: "single", 2: True}[args.buffers]
+                             if buffers is None else buffers,
                              obs_dtype=torch.float32 if args.obs_dtype == "float32" else torch.uint8,
                              placement_probe=placement_probe,
                              placement_budget_gib="all")  # this process owns the device: the zone walk may use all of it
@@ -197,7 +199,7 @@ class EngineStep:
         gen.manual_seed(1 + rank)
         self.pool = [torch.randint(0, 5, (batch, agents), generator=gen, device=device).to(tdt) for _ in range(32)]
         self.no_obs = args.no_obs
-        self.nbuf = args.buffers
+        self.nbuf = 2 if (args.buffers == 0 and args.graph > 0) else args.buffers
         self.graph = None
         self.graph_len = 0
         self.i = 0
@@ -228,8 +230,14 @@ class EngineStep:
 
     def describe_buffers(self):
         pl = getattr(self.env, "placement", None) or {}
+        rec = getattr(self.env, "_recycler", None)
+        if rec:
+            mode = (f"reuse_buffers='recycle' (product default): {len(rec)} output sets handed out as ordinary tensors and taken "
+                    f"back once dropped ({rec.taken} hand-outs, {rec.misses} fell back to fresh tensors); observation buffers")
+        else:
+            mode = f"{self.nbuf} alternating buffers" if self.nbuf == 2 else "one output set rewritten in place; buffer"
         if pl.get("method", "").startswith("pgx_buffers"):
-            return (f"{self.nbuf} alternating buffers from the engine's zone-aware pool ({pl.get('pools_tried', 1)} tried): halves in two HBM zones = {pl['spread']} "
+            return (f"{mode} from the engine's zone-aware pool ({pl.get('pools_tried', 1)} tried): halves in two HBM zones = {pl['spread']} "
                     f"(probe stream {pl['same_zone_us']:.1f} us same-zone -> {pl['final_us']:.1f} us as placed, "
                     f"{pl['candidates']} candidates, {pl['spacer_gib']:.0f} GiB of temporary spacers; plain store stream "
                     f"into the slowest buffer: {pl['buffer_gbs']:.0f} GB/s); observation stream timed into them "
@@ -238,7 +246,7 @@ class EngineStep:
                     f"observation pass {pl.get('observe_us_equal_shares')} -> {pl.get('observe_us_tuned_shares')} us")
         tuned = (f"; workgroups per XCD tuned to {pl['xcd_shares']}: observation pass {pl.get('observe_us_equal_shares')} -> "
                  f"{pl.get('observe_us_tuned_shares')} us") if pl.get("xcd_shares") else ""
-        return f"{self.nbuf} output buffer(s) as torch's allocator returned them (no zone placement){tuned}"
+        return f"{mode} as torch's allocator returned them (no zone placement){tuned}"
 
     def box_store_stream_gbs(self):
         """What a bare store stream sustains on THIS box where the buffers lie (the zone walk's probe: 2 x 384 MiB,
@@ -380,8 +388,11 @@ def main(argv=None):
     ap.add_argument("--auto-reset", default="restore", choices=["restore", "regenerate"],
                     help="restore = finished envs return to their initial state inside the step kernel (headline); "
                          "regenerate = they get a fresh random instance on the device (pgx_regenerate)")
-    ap.add_argument("--buffers", type=int, default=2, choices=[1, 2],
-                    help="output buffer sets: 2 alternating (default; step t's tensors survive step t+1) or 1 rewritten in place")
+    ap.add_argument("--buffers", type=int, default=0, choices=[0, 1, 2],
+                    help="output buffers: 0 = the product default (reuse_buffers='recycle': ordinary tensors from the engine's "
+                         "zone-spread pool, taken back when the caller has dropped them -- the loop drops each step's outputs "
+                         "before the next step, as a policy loop does); 2 = two alternating sets (step t's tensors are "
+                         "overwritten by step t+2); 1 = one set rewritten in place")
     ap.add_argument("--graph", type=int, default=0, help="capture this many steps in one HIP graph and replay it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-default-placement", action="store_true",
@@ -502,7 +513,7 @@ def main(argv=None):
     # secondary figures, never `value`: the same work without the launch boundary in the way
     extras = {}
     if (not args.stub and not args.no_extras and world == 1 and args.graph <= 0 and args.auto_reset == "restore"
-            and not args.no_obs and args.buffers == 2):
+            and not args.no_obs and args.buffers != 1):
         n = min(args.steps, 1000)
         extra_errors = {}
         if batch % 2 == 0:
@@ -545,9 +556,9 @@ def main(argv=None):
         # BASELINE.json's metric label only for BASELINE.json's workload as the product runs it: configs[2], float32,
         # 8192 envs on every GPU, one launch per step into two alternating buffers, observations written
         headline = (args.workload == "cfg2" and args.obs_dtype == "float32" and not args.stub and batch == per_gpu
-                    and args.global_batch == 0 and args.buffers == 2 and args.graph == 0 and not args.no_obs)
+                    and args.global_batch == 0 and args.buffers == 0 and args.graph == 0 and not args.no_obs)
         variant = "".join([f", {batch} envs per GPU" if args.global_batch == 0 else f", global batch {total_envs}",
-                           ", one output buffer" if args.buffers == 1 else "",
+                           {0: "", 1: ", one output set rewritten in place", 2: ", two alternating output sets"}[args.buffers],
                            f", hipGraph of {args.graph} steps" if args.graph > 0 else "",
                            ", NO observation write (diagnostic)" if args.no_obs else ""])
         line = {
@@ -568,7 +579,7 @@ def main(argv=None):
                        "sharding": f"batch-sharded x{world}, no collective",
                        "launch": f"hipGraph of {args.graph} steps" if args.graph > 0 else "one pgx_step launch per step",
                        "obs_buffers": step.describe_buffers()},
-            "roofline": {"bound": "hbm" if (args.buffers == 2 or alg_bytes > (200 << 20)) else "hbm (output tensor rewritten in place: largely Infinity-Cache resident)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm" if (args.buffers != 1 or alg_bytes > (200 << 20)) else "hbm (output tensor rewritten in place: largely Infinity-Cache resident)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "pgx::step_kernel", "kernel_ms": kernel_ms, "kernel_ms_per_rank": per_rank_kernel,
                          "kernel_ms_windows": kernel,

@@ -120,3 +120,71 @@ class ZoneBuffers:
         self.tensors[index] = None
         self.ring = None
         _lib.check(self._lib.pgx_buffers_drop(self._handle, int(index)))
+
+
+class RecyclingOutputs:
+    """Placement-aware output allocator: a few complete output SETS handed out as ORDINARY tensors.
+
+    A set is one observation tensor (a zone-spread pool buffer for large tensors, torch's own memory for small ones)
+    plus one small block carved into rewards f32 / terminated / truncated / is_active bool [batch, agents].  `take()`
+    returns the tensors of a set that nobody references any more, or None while every set is still referenced by the
+    caller (who then gets fresh torch tensors).  Nothing is ever overwritten behind the caller's back: a set is handed
+    out again only when the last tensor or view on ANY of its members has been dropped -- the semantics of torch's own
+    caching allocator, including its caveat: memory is re-used in the order of the stream the engine writes on, so a
+    consumer on ANOTHER stream must synchronise before dropping its reference (torch: Tensor.record_stream).
+
+    "Nobody references it" is read off the storages' reference counts (torch._C._storage_Use_Count, 0.15 us each); a
+    handed-out tensor is `master.detach()` (1 us) -- together half the host time of five torch.empty calls.  `available()`
+    says whether this torch build has the hook; without it the caller simply allocates fresh tensors."""
+
+    @staticmethod
+    def available() -> bool:
+        return hasattr(torch._C, "_storage_Use_Count")
+
+    def __init__(self, obs_tensors, batch: int, agents: int):
+        if not self.available():
+            raise RuntimeError("torch._C._storage_Use_Count is missing in this torch build")
+        self._count = torch._C._storage_Use_Count
+        dev = obs_tensors[0].device
+        n = batch * agents
+        self._sets = []
+        for obs in obs_tensors:
+            block = torch.empty(n * 7 + 16, dtype=torch.uint8, device=dev)  # f32 rewards first (alignment), then 3 x u8
+            members = (obs, block[:4 * n].view(torch.float32).view(batch, agents),
+                       block[4 * n:5 * n].view(torch.bool).view(batch, agents),
+                       block[5 * n:6 * n].view(torch.bool).view(batch, agents),
+                       block[6 * n:7 * n].view(torch.bool).view(batch, agents))
+            storages = (obs.untyped_storage(), block.untyped_storage())
+            self._sets.append((members, storages, tuple(st._cdata for st in storages)))
+        del obs, block, members, storages
+        self._idle = [tuple(self._count(c) for c in cdata) for _, _, cdata in self._sets]
+        self._next = 0
+        self.taken = 0      # statistics: sets handed out / requests that found every set in use
+        self.misses = 0
+
+    def __len__(self):
+        return len(self._sets)
+
+    def obs_pointers(self):
+        return [members[0].data_ptr() for members, _, _ in self._sets]
+
+    def _is_idle(self, i: int) -> bool:
+        cdata, idle = self._sets[i][2], self._idle[i]
+        return self._count(cdata[0]) == idle[0] and self._count(cdata[1]) == idle[1]
+
+    def free_sets(self) -> int:
+        return sum(self._is_idle(i) for i in range(len(self._sets)))
+
+    def take(self, with_obs: bool = True):
+        """(obs, rewards, terminated, truncated, is_active) of an unreferenced set -- least recently handed out first --
+        or None.  with_obs=False: obs is None (the set's observation buffer stays idle)."""
+        n = len(self._sets)
+        for k in range(n):
+            i = (self._next + k) % n
+            if self._is_idle(i):
+                self._next = (i + 1) % n
+                self.taken += 1
+                m = self._sets[i][0]
+                return (m[0].detach() if with_obs else None, m[1].detach(), m[2].detach(), m[3].detach(), m[4].detach())
+        self.misses += 1
+        return None

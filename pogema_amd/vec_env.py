@@ -54,11 +54,19 @@ class VecPogema:
                 'metrics': float32 [batch, 6] (ISR, CSR, ep_length, SoC, makespan, avg_throughput; a row is
                 refreshed on the step where its env's episode ends -- mask with 'episode_done')}
 
-    Throughput: pass `reuse_buffers=True` -- the outputs then live in two alternating, engine-probed buffers instead
-    of fresh allocations whose placement in HBM is arbitrary (the same kernel runs 140..153 us per step depending on
-    where its output buffer lives).  ALIASING: with `reuse_buffers=True` every tensor returned by step t (obs, rewards,
-    terminated, truncated, infos['is_active']) is overwritten by step t+2 -- consume or copy it before then, or hand
-    step() your own buffers with `out=`.  `reuse_buffers="single"`: one set only, overwritten by EVERY step.
+    Where the observation tensor lives in HBM decides up to a fifth of the step time (the same kernel runs
+    117..153 us per configs[2] step depending on its output buffer), so the engine allocates it (`reuse_buffers`):
+      "recycle" (default)  ordinary tensors, never overwritten behind your back: a few zone-spread buffers are handed
+                  out in turn and taken back only when you have dropped every reference to a tensor (and its views), as
+                  torch's own allocator does; while all of them are still referenced, fresh torch tensors are returned.
+                  (Observation tensors below 128 MiB live in torch's own memory, recycled the same way -- half the
+                  host time of allocating five tensors per step.)
+      True        two alternating output sets: every tensor returned by step t (obs, rewards, terminated, truncated,
+                  infos['is_active']) is OVERWRITTEN BY STEP t+2 -- consume or copy it before then.  Saves the per-step
+                  allocations of the small outputs as well; what bench.py measures.
+      "single"    one set only, overwritten by EVERY step (tensors up to ~200 MB then stay in the Infinity Cache).
+      False       a fresh torch tensor per step, wherever the allocator puts it.
+    Or hand step() your own buffers with `out=`.
     The buffers are picked on first use: a zone walk that holds up to `placement_budget_gib` of HBM for 1-2 s and
     synchronises the device.  Call `warm_buffers()` after reset() to have that happen at a moment of your choosing
     (required before capturing step() in a HIP graph); if the walk fails (another process took the memory meanwhile)
@@ -70,7 +78,7 @@ class VecPogema:
     """
 
     def __init__(self, grid_config: Optional[GridConfig] = None, batch: int = 1, device="cuda:0",
-                 env_index_base: int = 0, auto_reset: Optional[bool] = None, reuse_buffers: bool = False,
+                 env_index_base: int = 0, auto_reset: Optional[bool] = None, reuse_buffers="recycle",
                  obs_dtype=torch.float32, semantics: Optional[Semantics] = None,
                  placement_probe: Optional[bool] = None, placement_budget_gib=None):
         self.grid_config = grid_config if grid_config is not None else GridConfig(num_agents=2)
@@ -107,12 +115,16 @@ class VecPogema:
         # True: two alternating output sets; "single": ONE set, overwritten by every step (for callers that consume the
         # observation before the next step: a tensor of <= ~200 MB rewritten in place stays largely inside the 256 MiB
         # Infinity Cache -- configs[3]: bare stream 28 instead of 32 us)
-        if reuse_buffers not in (False, True, "single"):
-            raise ValueError("reuse_buffers must be False, True or 'single'")
+        if reuse_buffers is None:
+            reuse_buffers = "recycle"
+        if reuse_buffers not in (False, True, "single", "recycle"):
+            raise ValueError("reuse_buffers must be 'recycle', True, 'single' or False")
         self.single_buffer = reuse_buffers == "single"
+        self.recycle = reuse_buffers == "recycle"
+        self._recycler = None     # RecyclingOutputs once built; False = not available in this torch build
         self._rollout_pools = {}  # obs_slots -> ZoneBuffers of rollout()'s observation ring
         self.placement = None     # how the reused observation buffers were placed (set on first use)
-        self.reuse_buffers = bool(reuse_buffers)
+        self.reuse_buffers = reuse_buffers in (True, "single")
         self.semantics = semantics if semantics is not None else Semantics.from_env()
         # placement probe of the double-buffered observation tensors (reuse_buffers=True); PGX_PLACEMENT=0 disables
         self.placement_probe = (os.environ.get("PGX_PLACEMENT") != "0") if placement_probe is None else bool(placement_probe)
@@ -393,9 +405,10 @@ class VecPogema:
     # alternating 190 MB buffers exceed the cache together and gain 2-3 % from the pool.
     PLACEMENT_MIN_BYTES = int(os.environ.get("PGX_ZONE_MIN_MB", "128")) << 20
 
-    def _pick_obs_buffers(self):
+    def _pick_obs_buffers(self, n: Optional[int] = None):
         obs_bytes = int(np.prod(self.obs_shape)) * (4 if self.obs_dtype == torch.float32 else 1)
-        n = 1 if self.single_buffer else 2
+        if n is None:
+            n = 1 if self.single_buffer else 2
         if not self.placement_probe or obs_bytes < self.PLACEMENT_MIN_BYTES:
             return self._plain_obs_buffers(n)
         # The walk's verdict does not always carry over to the real buffers (halves may straddle a boundary), and some
@@ -475,15 +488,47 @@ class VecPogema:
             self.placement.update(self.tune_xcd_shares(bufs[0], bufs[-1] if n > 1 else None))
         return bufs
 
+    def _recycle_sets(self, obs_bytes: int) -> int:
+        """Output sets of reuse_buffers='recycle'.  A policy loop holds one observation while the next is written: two
+        sets serve it.  Tensors of 64-256 MiB get exactly two (two alternating 190 MB tensors still sit partly in the
+        256 MiB Infinity Cache, three do not: configs[3] 36.0 vs 41.0 us per step, profiles/r3/recycle_modes.txt); all
+        others a third one for callers that keep (obs, next_obs) pairs."""
+        return 2 if (64 << 20) <= obs_bytes < (256 << 20) else 3
+
+    def _build_recycler(self):
+        """reuse_buffers='recycle': False (fresh tensors) where the storage-count hook is missing or the walk failed."""
+        from .buffers import RecyclingOutputs
+        if not RecyclingOutputs.available():
+            return False
+        obs_bytes = int(np.prod(self.obs_shape)) * (4 if self.obs_dtype == torch.float32 else 1)
+        n = self._recycle_sets(obs_bytes)
+        if not self.placement_probe or obs_bytes < self.PLACEMENT_MIN_BYTES:
+            bufs = self._plain_obs_buffers(n)  # torch's own memory, XCD shares tuned for launches of >= 2048 envs
+        else:
+            bufs = self._pick_obs_buffers(n)   # zone walk, candidates timed, the best n kept
+        return RecyclingOutputs(bufs, self.batch, self.num_agents)
+
+    def _recycled(self, with_obs: bool = True):
+        """reuse_buffers='recycle': an unreferenced output set, else (all sets still referenced by the caller / inside a
+        graph capture, where memory must belong to the graph for good / before any state is installed) fresh tensors."""
+        capturing = torch.cuda.is_current_stream_capturing()
+        if self._recycler is None and self._has_state() and not capturing:
+            self._recycler = self._build_recycler()
+        out = self._recycler.take(with_obs) if (self._recycler and not capturing) else None
+        return out if out is not None else self._alloc_outputs(with_obs)
+
     def warm_buffers(self) -> dict:
-        """Pick the reused output buffers NOW (reuse_buffers=True / "single"; a no-op otherwise or when already done):
+        """Pick the engine-allocated output buffers NOW (a no-op for reuse_buffers=False or when already done):
         zone walk, timing of the candidates, XCD share tuning -- 1-3 s during which up to `placement_budget_gib` of HBM
         is held and the device is synchronised.  Without this call the first step() does it.  Needs an installed state
         (reset() first) to time the real observation stream; returns `placement`."""
+        if torch.cuda.is_current_stream_capturing() and ((self.reuse_buffers and self._bufs is None) or
+                                                         (self.recycle and self._recycler is None)):
+            raise RuntimeError("warm_buffers() synchronises the device: call it before the graph capture starts")
         if self.reuse_buffers and self._bufs is None:
-            if torch.cuda.is_current_stream_capturing():
-                raise RuntimeError("warm_buffers() synchronises the device: call it before the graph capture starts")
             self._bufs = [(obs,) + self._alloc_outputs(False)[1:] for obs in self._pick_obs_buffers()]
+        elif self.recycle and self._recycler is None and self._has_state():
+            self._recycler = self._build_recycler()
         return self.placement or {}
 
     def tune_xcd_shares(self, obs: torch.Tensor, obs_alt: Optional[torch.Tensor] = None, rounds: int = 6) -> dict:
@@ -516,9 +561,11 @@ class VecPogema:
     def _has_state(self):
         return self._initial is not None
 
-    def _outputs(self):
+    def _outputs(self, with_obs: bool = True):
+        if self.recycle:
+            return self._recycled(with_obs)
         if not self.reuse_buffers:
-            return self._alloc_outputs()
+            return self._alloc_outputs(with_obs)
         if self._bufs is None:
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("reuse_buffers: the output buffers are picked by a timed zone walk that synchronises "
@@ -528,7 +575,12 @@ class VecPogema:
         return self._bufs[self._buf_i]
 
     def observe(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        obs = out if out is not None else torch.empty(self.obs_shape, dtype=self.obs_dtype, device=self.device)
+        if out is not None:
+            obs = out
+        elif self.recycle:
+            obs = self._recycled()[0]
+        else:
+            obs = torch.empty(self.obs_shape, dtype=self.obs_dtype, device=self.device)
         if obs.dtype != self.obs_dtype or tuple(obs.shape) != self.obs_shape or not obs.is_contiguous():
             raise ValueError(f"`out` must be a contiguous {self.obs_dtype} tensor of shape {self.obs_shape}")
         _lib.check(self._lib.pgx_observe(self._handle, obs.data_ptr(), self._stream()))
@@ -566,8 +618,9 @@ class VecPogema:
         """One step of every environment.  `actions`: int tensor [batch, agents] with values 0..4
         (noop, up, down, left, right).  Returns (obs, rewards, terminated, truncated, infos).
 
-        Output buffers: fresh tensors per call by default; with `reuse_buffers=True` two alternating sets, so whatever
-        step t returned is OVERWRITTEN BY STEP t+2 (consume or copy it before); with
+        Output buffers (class docstring, `reuse_buffers`): by default tensors that are yours for as long as you reference
+        them; with `reuse_buffers=True` two alternating sets, so whatever step t returned is OVERWRITTEN BY STEP t+2
+        (consume or copy it before); with
         `out=(obs, rewards, terminated, truncated, is_active)` the caller's own tensors are written (bool or uint8
         flags; `obs` may be None together with compute_obs=False) and returned.
 
@@ -582,7 +635,7 @@ class VecPogema:
             if compute_obs and obs is None:
                 raise ValueError("out[obs] is None but compute_obs=True")
         else:
-            obs, rewards, terminated, truncated, is_active = self._outputs()
+            obs, rewards, terminated, truncated, is_active = self._outputs(compute_obs)
         _lib.check(self._lib.pgx_step(
             self._handle, actions.data_ptr(), self._ACTION_CODE[actions.dtype],
             obs.data_ptr() if compute_obs else None, rewards.data_ptr(), terminated.data_ptr(),

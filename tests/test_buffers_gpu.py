@@ -146,3 +146,82 @@ def test_address_space_accounting():
         ptrs.append(pool.tensors[0].data_ptr())
         del pool, t
     assert len(set(ptrs)) == 3, "a released range is not handed out again"
+
+
+def test_recycle_mode_never_aliases_and_takes_sets_back():
+    """reuse_buffers='recycle' (the default): outputs come from a few recycled sets (zone-spread observation buffers for
+    large tensors), a set is handed out again only when the caller has dropped every reference to every member (views
+    included), and while all are held the engine falls back to fresh tensors -- results identical to
+    reuse_buffers=False throughout."""
+    import gc as pygc
+    import torch
+    from pogema_amd import GridConfig, VecPogema
+    cfg = GridConfig(size=32, num_agents=32, obs_radius=5, density=0.3, seed=3, collision_system="soft")
+    B = 512
+    ref = VecPogema(cfg, batch=B, auto_reset=True, reuse_buffers=False)
+    env = VecPogema(cfg, batch=B, auto_reset=True)  # default
+    assert env.recycle and not env.reuse_buffers
+    env.PLACEMENT_MIN_BYTES = 1 << 20  # 23.8 MB per tensor: force the pool path
+    ref.reset(seed=3)
+    first, _ = env.reset(seed=3)
+    rec = env._recycler
+    assert rec and len(rec) == 3 and env.placement["method"].startswith("pgx_buffers")
+    pool_ptrs = set(rec.obs_pointers())
+    assert first.data_ptr() in pool_ptrs
+    acts = torch.randint(0, 5, (9, B, 32), device="cuda", dtype=torch.int8)
+    held, expect = [first], [ref.observe()]
+    for t in range(5):  # hold everything: 3 sets, then fresh tensors; nothing may be overwritten
+        held.append(env.step(acts[t])[0])
+        expect.append(ref.step(acts[t])[0])
+    assert len({h.data_ptr() for h in held}) == len(held)
+    assert sum(h.data_ptr() in pool_ptrs for h in held) == len(rec) and rec.misses == len(held) - len(rec)
+    for h, e in zip(held, expect):
+        assert torch.equal(h, e)
+    view = held[1][3, 2]           # a view keeps its set out of circulation
+    kept_ptr = held[1].data_ptr()
+    del held, h, first
+    pygc.collect()
+    assert rec.free_sets() == len(rec) - 1
+    got = [env.step(acts[5])[0], env.step(acts[6])[0], env.step(acts[7])[0]]
+    want = [ref.step(acts[5])[0], ref.step(acts[6])[0], ref.step(acts[7])[0]]
+    assert kept_ptr not in {g.data_ptr() for g in got} and all(torch.equal(g, w) for g, w in zip(got, want))
+    assert torch.equal(view, expect[1][3, 2])
+    # a small member alone (rewards) keeps its set out as well
+    del got, view
+    pygc.collect()
+    assert rec.free_sets() == len(rec)
+    _, rewards, *_ = env.step(acts[8])
+    want_r = ref.step(acts[8])[1]
+    assert rec.free_sets() == len(rec) - 1 and torch.equal(rewards, want_r)
+    # the memory outlives the environment for as long as a tensor references it
+    env.close()
+    del env, rec
+    pygc.collect()
+    assert torch.equal(rewards, want_r)
+    ref.close()
+
+
+def test_recycle_mode_small_tensors_and_missing_hook(monkeypatch):
+    """Small observation tensors are recycled from torch's own memory (no zone walk); without the storage-count hook the
+    mode degrades to fresh tensors per step."""
+    import torch
+    from pogema_amd import GridConfig, VecPogema, buffers
+    cfg = GridConfig(size=16, num_agents=8, obs_radius=3, density=0.2, seed=1)
+    acts = torch.randint(0, 5, (64, 8), device="cuda", dtype=torch.int8)
+    env = VecPogema(cfg, batch=64, auto_reset=True)
+    env.reset(seed=1)
+    assert env._recycler and env.placement["method"] == "torch allocator"
+    ptrs = set()
+    for _ in range(12):
+        obs = env.step(acts)[0]
+        ptrs.add(obs.data_ptr())
+    assert len(ptrs) <= len(env._recycler) and env._recycler.misses == 0
+    env.close()
+    monkeypatch.setattr(buffers.RecyclingOutputs, "available", staticmethod(lambda: False))
+    env = VecPogema(cfg, batch=64, auto_reset=True)
+    env.reset(seed=1)
+    assert env._recycler is False
+    a = env.step(acts)[0]
+    b = env.step(acts)[0]
+    assert a.data_ptr() != b.data_ptr()
+    env.close()

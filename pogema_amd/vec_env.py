@@ -172,7 +172,11 @@ class VecPogema:
         except Exception:
             pass
 
+    _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)  # 0.1 us; torch.cuda.current_stream(): 2 us
+
     def _stream(self):
+        if self._raw_stream is not None:
+            return C.c_void_p(self._raw_stream(self.device_index))
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     @property

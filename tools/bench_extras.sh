@@ -1,5 +1,5 @@
 #!/bin/bash
-# bench lines with secondary figures for the three GPU configurations (round-2 evidence)
+# bench lines with secondary figures for the three GPU configurations (round-2 and round-3 evidence)
 mkdir -p gpurun_out
 for wl in cfg2 cfg3 cfg4 cfg1; do
   steps=2000; [ $wl = cfg4 ] && steps=500

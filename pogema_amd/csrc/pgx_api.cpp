@@ -244,7 +244,6 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
         err = pgx::launch_init_np_lifelong(e->np_state0, cfg->seed, cfg->env_index_base, cfg->batch, A, nullptr);
     if (err == hipSuccess && e->np_state0) err = hipStreamSynchronize(nullptr);
     if (err == hipSuccess) err = pgx::prepare_step(e->geo, e->geo_roll);
-    if (err == hipSuccess) err = pgx::prepare_persist(e->geo, cfg->batch);
     if (const char* spec = getenv("PGX_XCD_WEIGHTS")) {  // eight comma-separated weights (diagnostic)
         float f[8], sum = 0.f;
         if (sscanf(spec, "%f,%f,%f,%f,%f,%f,%f,%f", &f[0], &f[1], &f[2], &f[3], &f[4], &f[5], &f[6], &f[7]) == 8) {
@@ -908,17 +907,6 @@ int pgx_get_state(pgx_env* e, int32_t* agent_xy, int32_t* target_xy, uint8_t* is
 int pgx_xcd_shares(pgx_env* e, int32_t* shares) {
     if (!e || !shares) return fail(PGX_E_INVALID, "pgx_xcd_shares: null argument");
     for (int x = 0; x < 8; ++x) shares[x] = e->geo.xcd_n[x];
-    return PGX_OK;
-}
-
-// Diagnostic only (not part of include/pogema_amd.h): how pgx_step launches -- {persistent kernel in use, its grid,
-// waves per workgroup, environments per wave of the one-workgroup-per-slice kernel}.
-int pgx_debug_launch_shape(pgx_env* e, int32_t* out4) {
-    if (!e || !out4) return fail(PGX_E_INVALID, "pgx_debug_launch_shape: null argument");
-    out4[0] = e->geo.persist ? 1 : 0;
-    out4[1] = e->geo.persist ? e->geo.persist_grid : e->geo.grid;
-    out4[2] = e->geo.waves;
-    out4[3] = e->geo.epw;
     return PGX_OK;
 }
 

@@ -67,7 +67,6 @@ struct StepParams {
     int32_t obs_u8;    // 1: `obs` is uint8 (one byte per cell) instead of float32
     int32_t stagger;   // cohort stagger of the single-wave kernel (StepGeometry::stagger)
     int32_t store_policy;  // observation stores: 0 plain, 1 nontemporal, 2 sc1 write-through (StepGeometry::store_policy)
-    int32_t persist_state_words, persist_rows_words, persist_share0;  // step_persist_kernel: LDS layout, producer's stream share [%]
     int32_t state_stores;  // when the small per-step result stores are issued: 0 at once, 1 after the LDS barrier, 2 after the stream
     int32_t soft_rule;    // PGX_SOFT_*  (docs/SPEC.md Q1)
     int32_t coop_reward;  // PGX_COOP_REWARD_* (Q4)
@@ -131,9 +130,6 @@ struct StepGeometry {
     int stagger;      // > 0: odd wave slots sleep this many x 8128 cycles after issuing their loads
     int store_policy; // observation store flavour (pgx_kernels.hip: store_obs16)
     int state_stores; // when the per-step result stores are issued (pgx_kernels.hip: emit_state)
-    bool persist;     // large launches of 64-agent-class environments: one resident round of persistent workgroups
-    int persist_grid, persist_state_words, persist_rows_words, persist_share0;
-    size_t persist_lds;
     size_t lds_bytes;
     // shares of the launch's workgroups per XCD (xcd_partition; equal until pgx_xcd_tune or PGX_XCD_WEIGHTS)
     int grid;             // workgroups to launch: 8 * the largest share
@@ -143,7 +139,6 @@ StepGeometry step_geometry(int batch, int A, int bmw, int W, bool allow_p16, int
                            int waves_override, bool for_rollout = false);
 hipError_t prepare_step(const StepGeometry& g, const StepGeometry& roll);
 hipError_t launch_step(const StepParams& p, const StepGeometry& g, hipStream_t stream);
-hipError_t prepare_persist(StepGeometry& g, int blocks);
 // splits `blocks` workgroups over the XCDs by `w`; returns the grid size (8 * the largest share)
 int xcd_partition(int blocks, const float w[8], int32_t n[8], int32_t base[8]);
 hipError_t launch_rollout(const StepParams& p, const RolloutParams& rp, const StepGeometry& g, hipStream_t stream);

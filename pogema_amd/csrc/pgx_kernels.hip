@@ -313,12 +313,8 @@ enum { MISC_FLAGS = 0, MISC_ARRIVED = 16, MISC_UNSOLVED = 17, MISC_OFFGOAL = 18,
 // kernarg pointer (rollout_kernel).  ROLL: step `t` of a pgx_rollout launch -- the per-step I/O tensors are slices t of
 // the caller's [K, ...] buffers (observations: ring slot `slot`), addressed where they are used so that nothing but `t`
 // and `slot` lives across the loop.
-// PRODUCE (step_persist_kernel): the calling wave is the PRODUCER of a persistent workgroup -- it takes slice `pblk`
-// through phases 0..3 of the single-wave kernel and leaves the packed row masks in `prows` instead of streaming them.
-template <int G, bool MW, bool P16, bool ROLL, bool PRODUCE = false, typename P, typename R>
-__device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int slot, const int pblk = 0,
-                                          uint16_t* prows = nullptr) {
-    static_assert(!PRODUCE || (!MW && P16 && !ROLL), "the producer role is the single-wave P16 state phase");
+template <int G, bool MW, bool P16, bool ROLL, typename P, typename R>
+__device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int slot) {
     static_assert(!MW || G == 64, "multi-wave environments use full waves");
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
 
@@ -338,9 +334,8 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
     // ASSUMPTION: blockIdx & 7 is the XCD -- true in SPX mode with 8 XCDs (round-robin dispatch of consecutive
     // workgroups), which is how this pool's MI355X run.  In a partitioned mode (CPX/DPX ...) the mapping still covers
     // every slice exactly once (results are unaffected); only the contiguity-per-L2 and the tuned shares lose their meaning.
-    int blk = PRODUCE ? pblk : (int)blockIdx.x;
-    if constexpr (PRODUCE) {
-    } else if (!(p.flags & 8u)) {
+    int blk = blockIdx.x;
+    if (!(p.flags & 8u)) {
         // PGX_FLAGS bits 10..12 (diagnostic): XCD x takes the share of XCD (x + rot) & 7 -- does a slow XCD stay slow?
         const int x = ((blk & 7) + (int)((p.flags >> 10) & 7u)) & 7, k = blk >> 3;
         if (k >= p.xcd_n[x]) return;
@@ -350,7 +345,7 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
     }
     const int env0 = blk * epw;
     const int nenv = min(epw, p.batch - env0);
-    if (!PRODUCE && p.only) {  // masked observe (after pgx_regenerate): untouched environments keep their observation
+    if (p.only) {  // masked observe (after pgx_regenerate): untouched environments keep their observation
         bool any = false;
         for (int el = 0; el < nenv; ++el) any = any || p.only[env0 + el] != 0;
         if (!any) return;
@@ -459,7 +454,7 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
         bool trunc = false, finished = false, do_reset = false, act = false;
         int n_arrived = 0;
     } so;
-    const int when_stores = p.mode == MODE_STEP ? (PRODUCE ? min(p.state_stores, 1) : p.state_stores) : 0;
+    const int when_stores = p.mode == MODE_STEP ? p.state_stores : 0;
     const bool late_stores = when_stores != 0;
     auto emit_state = [&](uint32_t pos_, uint32_t tgt_, bool active_, int elapsed_, int4 macc_, const StateOut& o) {
         const bool fin = p.on_target == ON_TARGET_FINISH, coop = p.on_target == ON_TARGET_NOTHING;
@@ -744,7 +739,7 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
             }
         }
         lds_sync<MW>();  // every lane has read the bitmaps / agent cells: the region may be overwritten
-        uint16_t* rows16 = PRODUCE ? prows : reinterpret_cast<uint16_t*>(smem);
+        uint16_t* rows16 = reinterpret_cast<uint16_t*>(smem);
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             const int item = tid + t * NT;
@@ -756,7 +751,6 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
         }
         if (tid < 4) rows16[nag * 3 * W + tid] = 0;
         lds_sync<MW>();
-        if constexpr (PRODUCE) return;  // the workgroup's consumers stream them (step_persist_kernel)
 
         // ---- phase 4 (P16): stream the observations --------------------------------------------------------
         const int n = nag * 3 * W * W;
@@ -893,68 +887,6 @@ template <int G, bool MW, bool P16>
 __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const StepParams p) {
     const RolloutParams none{};
     step_body<G, MW, P16, false>(p, none, 0, 0);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Persistent workgroups for large launches of 64-agent-class environments (33..64 agents, window <= 16, float32):
-// the launch is ONE resident round of 3-wave workgroups, and every workgroup takes its slices one after the other as a
-// two-stage pipeline -- wave 0 PRODUCES slice i (loads, collision resolve, state stores, row masks: the single-wave state
-// phase, into one of two row buffers in LDS) while waves 1 and 2 CONSUME slice i-1 (the observation stream out of the
-// other buffer); wave 0 streams a smaller share of slice i-1 when it is done producing.  One barrier per slice.
-// Why: in the one-workgroup-per-environment launch a workgroup's prologue takes 16-18 us under load and only ~37 % of
-// the resident workgroups are streaming at any time; that costs nothing while HBM is saturated anyway, but the last
-// workgroups of the launch run their prologues into an emptying chip (DESIGN.md 4 "Round 3": ~8 us of 116).  Here no
-// stream ever waits for a prologue except the first one of each workgroup.
-// XCD x's workgroups (blockIdx & 7 == x) share out ITS slices [xcd_base, xcd_base + xcd_n): workgroup k of `per` takes
-// k, k + per, k + 2 per, ... -- the band of slices being written moves through the XCD's eighth of the tensor.
-__global__ __launch_bounds__(192, 6) void step_persist_kernel(const StepParams p0) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    typedef const __attribute__((address_space(4))) char KC;
-    typedef const __attribute__((address_space(4))) StepParams KP;
-    const RolloutParams none{};
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int x = blockIdx.x & 7, k = blockIdx.x >> 3, per = (int)(gridDim.x >> 3);
-    const int n_x = p0.xcd_n[x], first = p0.xcd_base[x] + k;
-    const int cnt = k < n_x ? (n_x - k + per - 1) / per : 0;
-    for (int i = 0; i <= cnt; ++i) {
-        // the argument block is re-read through a laundered kernarg pointer in every iteration: otherwise LICM hoists
-        // every argument load and address computation of the inlined state phase out of the loop (94 VGPRs, 154 spilled
-        // SGPRs instead of the single step's ~50 / 0) -- as in rollout_kernel
-        KC* ka = (KC*)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+s"(ka));
-        KP& p = *reinterpret_cast<KP*>(ka);
-        uint32_t* const rowbuf = smem + p.persist_state_words;
-        if (wave == 0 && i < cnt)
-            step_body<64, false, true, false, true>(p, none, 0, 0, first + i * per,
-                                                    reinterpret_cast<uint16_t*>(rowbuf + (i & 1) * p.persist_rows_words));
-        if (i > 0) {
-            const int blk = first + (i - 1) * per;
-            const int W = 2 * p.r + 1;
-            const int n = p.num_agents * 3 * W * W;  // floats per slice (one environment)
-            const uint32_t* rows32 = rowbuf + ((i - 1) & 1) * p.persist_rows_words;
-            const size_t base = (size_t)blk * n;
-            float* out = p.obs + base;
-            const int head = min(n, (int)((4 - (base & 3)) & 3));
-            const int nvec = (n - head) >> 2;
-            const bool dbg = (p.flags & 4u) && p.dbg;
-            if (wave == 1) {
-                stream_rows16_edges(out, reinterpret_cast<const uint16_t*>(rows32), n, head, head + (nvec << 2), W, p.w_magic, lane);
-                if (dbg && lane == 0) p.dbg[(size_t)blk * 4 + 2] = wall_clock64();
-            }
-            // shares in store instructions (64 float4 each): the producer takes the END of the slice, waves 1 / 2 halve the rest
-            const int chunks = (nvec + 63) >> 6;
-            const int c0 = chunks * p.persist_share0 / 100, c1 = (chunks - c0 + 1) >> 1;
-            const int lo = wave == 1 ? 0 : wave == 2 ? c1 : chunks - c0;
-            const int hi = wave == 1 ? c1 : wave == 2 ? chunks - c0 : chunks;
-            stream_rows16_span(reinterpret_cast<f32x4_t*>(out + head), rows32, head, W, p.w_magic, (uint32_t)p.store_policy,
-                               (lo << 6) + lane, min(nvec, hi << 6), 64);
-            if (dbg && wave == 2 && lane == 0) {
-                __builtin_amdgcn_s_waitcnt(0);
-                p.dbg[(size_t)blk * 4 + 3] = wall_clock64();
-            }
-        }
-        lds_sync<true>();
-    }
 }
 
 // K steps in ONE launch (pgx_rollout).  Environments never interact, so a workgroup can run its own environments
@@ -1170,26 +1102,6 @@ StepGeometry step_geometry(int batch, int A, int bmw, int W, bool allow_p16, int
         if (epw_override > 0) g.epw = epw_override < max_epw ? epw_override : max_epw;
     }
     g.p16 = allow_p16 && W <= 16;
-    // Persistent 3-wave workgroups (step_persist_kernel) where the three-wave rule above applies; the grid (one resident
-    // round) is filled in by prepare_persist().  PGX_PERSIST=0/1 overrides.
-    g.persist = false;
-    g.persist_grid = 0;
-    const int persist_env = getenv("PGX_PERSIST") ? atoi(getenv("PGX_PERSIST")) : -1;  // 2: whatever the launch size (tests)
-    if (persist_env == 2 && !g.multi_wave && A <= 64 && A > 32 && !for_rollout && waves_override <= 0) {
-        g.multi_wave = true;  // the fallback kernel of such a handle (masked observes, compute_obs=False) is the 3-wave one
-        g.waves = 3;
-        g.G = 64;
-        g.epw = 1;
-    }
-    if (g.multi_wave && g.waves == 3 && A <= 64 && A > 32 && g.p16 && obs_elem_bytes == 4 && !for_rollout &&
-        (batch >= 2048 || persist_env == 2)) {
-        const char* f = getenv("PGX_PERSIST");
-        g.persist = f ? atoi(f) != 0 : false;  // experiment: off unless asked for
-        g.persist_state_words = (int)(((size_t)2 * bmw + 2 * (size_t)A + 3) & ~(size_t)3);
-        g.persist_rows_words = (int)((((size_t)A * 3 * W + 4) * 2 + 15) / 16 * 4);
-        g.persist_lds = ((size_t)g.persist_state_words + 2 * (size_t)g.persist_rows_words) * 4;
-        g.persist_share0 = getenv("PGX_PSHARE") ? atoi(getenv("PGX_PSHARE")) : 16;
-    }
     g.store_policy = g.multi_wave ? 1 : 2;  // see store_obs16()
     // The small per-step result stores go out after the LDS barrier (emit_state(), mode 1): in-process A/B on shared
     // buffers (profiles/r3/state_stores_ab.txt) configs[3] 39.9 -> 39.1 us, configs[2] 115.7 -> 115.1, configs[1]/[4]
@@ -1289,32 +1201,7 @@ int xcd_partition(int blocks, const float w[8], int32_t n[8], int32_t base[8]) {
     return grid * 8;
 }
 
-// one resident round of step_persist_kernel workgroups on the current device (0: do not use it)
-hipError_t prepare_persist(StepGeometry& g, int blocks) {
-    if (!g.persist) return hipSuccess;
-    const void* fn = reinterpret_cast<const void*>(&step_persist_kernel);
-    if (hipError_t e = raise_lds_limit(fn, g.persist_lds)) return e;
-    int dev = 0, cus = 0, per_cu = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 192, g.persist_lds);
-    if (e != hipSuccess) return e;
-    if (const char* f = getenv("PGX_PERSIST_PER_CU")) per_cu = atoi(f) < per_cu ? atoi(f) : per_cu;
-    g.persist_grid = (cus * per_cu) & ~7;
-    if (g.persist_grid <= 0 || g.persist_grid >= blocks) g.persist = false;  // everything fits one round anyway
-    return hipSuccess;
-}
-
 hipError_t launch_step(const StepParams& p, const StepGeometry& g, hipStream_t stream) {
-    if (g.persist && p.obs && !p.only && !p.obs_u8 && !(p.flags & 8u)) {
-        StepParams args = p;
-        args.persist_state_words = g.persist_state_words;
-        args.persist_rows_words = g.persist_rows_words;
-        args.persist_share0 = g.persist_share0;
-        void* kargs[] = {&args};
-        return hipLaunchKernel(reinterpret_cast<const void*>(&step_persist_kernel), dim3(g.persist_grid), dim3(192), kargs,
-                               g.persist_lds, stream);
-    }
     const void* fn = step_fn_for(g);
     if (!fn) return hipErrorInvalidValue;
     StepParams args = p;

@@ -18,7 +18,7 @@ variants = sys.argv[2:]
 batch, size, agents, r = WL[wl]
 envs = []
 for v in variants:
-    for k in ("PGX_FLAGS", "PGX_EPW", "PGX_STAGGER", "PGX_LDS_MIN", "PGX_WAVES", "PGX_STORE", "PGX_TEAM", "PGX_STATE_STORES", "PGX_PERSIST", "PGX_PSHARE", "PGX_PERSIST_PER_CU"):
+    for k in ("PGX_FLAGS", "PGX_EPW", "PGX_STAGGER", "PGX_LDS_MIN", "PGX_WAVES", "PGX_STORE", "PGX_TEAM", "PGX_STATE_STORES"):
         os.environ.pop(k, None)
     for kv in v.split(","):
         if kv:

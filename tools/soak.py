@@ -16,7 +16,7 @@ B, A, size, r = 8192, 64, 64, 5
 for on_target, collision in (("finish", "soft"), ("restart", "priority"), ("nothing", "block_both")):
     gc = GridConfig(size=size, num_agents=A, obs_radius=r, density=0.3, seed=0, collision_system=collision, on_target=on_target,
                     max_episode_steps=48)
-    env = VecPogema(gc, batch=B, auto_reset=True, reuse_buffers=True)
+    env = VecPogema(gc, batch=B, auto_reset=True)  # product default: recycled output sets
     obs, _ = env.reset(seed=0)
     obstacles, agents, targets = (v.cpu().numpy() for v in env._initial)
     st = env.get_state()

@@ -65,7 +65,9 @@ class VecPogema:
                   infos['is_active']) is OVERWRITTEN BY STEP t+2 -- consume or copy it before then.  Saves the per-step
                   allocations of the small outputs as well; what bench.py measures.
       "single"    one set only, overwritten by EVERY step (tensors up to ~200 MB then stay in the Infinity Cache).
-      False       a fresh torch tensor per step, wherever the allocator puts it.
+      False       a fresh torch tensor per step, wherever the allocator puts it.  (Also the choice when observation
+                  tensors are handed to ANOTHER PROCESS through CUDA IPC: pool buffers are HIP virtual-memory mappings,
+                  which hipIpcGetMemHandle does not export.)
     Or hand step() your own buffers with `out=`.
     The buffers are picked on first use: a zone walk that holds up to `placement_budget_gib` of HBM for 1-2 s and
     synchronises the device.  Call `warm_buffers()` after reset() to have that happen at a moment of your choosing

@@ -225,3 +225,29 @@ def test_recycle_mode_small_tensors_and_missing_hook(monkeypatch):
     b = env.step(acts)[0]
     assert a.data_ptr() != b.data_ptr()
     env.close()
+
+
+@pytest.mark.parametrize("budget", [0, 1.0, "all"])
+def test_placement_budget_parameter(budget):
+    """VecPogema(placement_budget_gib=...): 0 = no walk (buffers still come from the pool, unspread), a number = GiB the
+    walk may hold, "all" = everything but the engine's reserve; results are the same tensors either way."""
+    import torch
+    from pogema_amd import GridConfig, VecPogema
+    cfg = GridConfig(size=32, num_agents=32, obs_radius=5, density=0.3, seed=5, collision_system="priority")
+    B = 3000  # 139 MB per observation tensor: the pool path without an override
+    env = VecPogema(cfg, batch=B, auto_reset=True, placement_budget_gib=budget)
+    ref = VecPogema(cfg, batch=B, auto_reset=True, reuse_buffers=False)
+    o, _ = env.reset(seed=5)
+    r, _ = ref.reset(seed=5)
+    assert torch.equal(o, r)
+    pl = env.placement
+    assert pl["method"].startswith("pgx_buffers")
+    if budget == 0:
+        assert pl["budget_gib"] == 0 and pl["candidates"] == 0 and not pl["spread"]
+    elif budget == 1.0:
+        assert pl["budget_gib"] == 1.0 and pl["spacer_gib"] <= 1.0
+    acts = torch.randint(0, 5, (3, B, 32), device="cuda", dtype=torch.int8)
+    for t in range(3):
+        a, b = env.step(acts[t]), ref.step(acts[t])
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    env.close(); ref.close()

@@ -62,8 +62,8 @@ class VecPogema:
                   (Observation tensors below 128 MiB live in torch's own memory, recycled the same way -- half the
                   host time of allocating five tensors per step.)
       True        two alternating output sets: every tensor returned by step t (obs, rewards, terminated, truncated,
-                  infos['is_active']) is OVERWRITTEN BY STEP t+2 -- consume or copy it before then.  Saves the per-step
-                  allocations of the small outputs as well; what bench.py measures.
+                  infos['is_active']) is OVERWRITTEN BY STEP t+2 -- consume or copy it before then.  Saves 2-3 us of host
+                  time per step() against the default (bench.py --buffers 2).
       "single"    one set only, overwritten by EVERY step (tensors up to ~200 MB then stay in the Infinity Cache).
       False       a fresh torch tensor per step, wherever the allocator puts it.  (Also the choice when observation
                   tensors are handed to ANOTHER PROCESS through CUDA IPC: pool buffers are HIP virtual-memory mappings,

@@ -494,7 +494,8 @@ class VecPogema:
             self.placement.update(self.tune_xcd_shares(bufs[0], bufs[-1] if n > 1 else None))
         return bufs
 
-    def _recycle_sets(self, obs_bytes: int) -> int:
+    @staticmethod
+    def _recycle_sets(obs_bytes: int) -> int:
         """Output sets of reuse_buffers='recycle'.  A policy loop holds one observation while the next is written: two
         sets serve it.  Tensors of 64-256 MiB get exactly two (two alternating 190 MB tensors still sit partly in the
         256 MiB Infinity Cache, three do not: configs[3] 36.0 vs 41.0 us per step, profiles/r3/recycle_modes.txt); all

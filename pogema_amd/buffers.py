@@ -8,8 +8,10 @@ released when the last tensor AND the pool object are gone.
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 import os
+import threading
 
 import numpy as np
 import torch
@@ -122,6 +124,60 @@ class ZoneBuffers:
         _lib.check(self._lib.pgx_buffers_drop(self._handle, int(index)))
 
 
+class ParkedBuffers:
+    """Process-wide shelf for the observation buffers of CLOSED environments (reuse_buffers='recycle').
+
+    Picking zone-spread buffers costs a walk of 1-3 s, and a pool's address ranges are never handed back to the driver
+    (DESIGN.md 4b), so a process that creates environments in a loop -- sweeps, test suites, evaluation workers --
+    would pay the walk and leak address space every time.  Instead `VecPogema.close()` parks the buffers nobody references
+    any more, still mapped, and the next environment with the same observation tensor on the same device takes them over
+    without a walk.  At most PGX_POOL_CACHE_MB (default 6144; 0 = off) stay parked, oldest first out; `clear()` empties
+    the shelf (the memory is then released with the last reference, as always)."""
+
+    _lock = threading.Lock()
+    _shelf = collections.OrderedDict()  # key -> [(tensor, placement info), ...]
+
+    @staticmethod
+    def limit_bytes() -> int:
+        return int(os.environ.get("PGX_POOL_CACHE_MB", "6144")) << 20
+
+    @classmethod
+    def _bytes(cls) -> int:
+        return sum(t.numel() * t.element_size() for items in cls._shelf.values() for t, _ in items)
+
+    @classmethod
+    def park(cls, key, tensors, info) -> int:
+        limit = cls.limit_bytes()
+        if limit <= 0 or not tensors:
+            return 0
+        with cls._lock:
+            cls._shelf.setdefault(key, []).extend((t, dict(info)) for t in tensors)
+            cls._shelf.move_to_end(key)
+            while cls._shelf and cls._bytes() > limit:  # oldest key first, one buffer at a time
+                old = next(iter(cls._shelf))
+                cls._shelf[old].pop(0)
+                if not cls._shelf[old]:
+                    del cls._shelf[old]
+            return len(cls._shelf.get(key, ()))
+
+    @classmethod
+    def claim(cls, key, n):
+        """n parked buffers for `key` as ([tensors], info of the first one), or None when fewer are parked."""
+        with cls._lock:
+            items = cls._shelf.get(key)
+            if not items or len(items) < n:
+                return None
+            taken = [items.pop() for _ in range(n)]
+            if not items:
+                del cls._shelf[key]
+            return [t for t, _ in taken], taken[0][1]
+
+    @classmethod
+    def clear(cls):
+        with cls._lock:
+            cls._shelf.clear()
+
+
 class RecyclingOutputs:
     """Placement-aware output allocator: a few complete output SETS handed out as ORDINARY tensors.
 
@@ -174,6 +230,17 @@ class RecyclingOutputs:
 
     def free_sets(self) -> int:
         return sum(self._is_idle(i) for i in range(len(self._sets)))
+
+    def retire(self):
+        """The observation buffers nobody outside the pool references any more, removed from circulation (for
+        ParkedBuffers when the environment closes); sets that are still referenced stay and die with their last user."""
+        idle = [i for i in range(len(self._sets)) if self._is_idle(i)]
+        out = [self._sets[i][0][0] for i in idle]
+        for i in reversed(idle):
+            del self._sets[i]
+            del self._idle[i]
+        self._next = 0
+        return out
 
     def take(self, with_obs: bool = True):
         """(obs, rewards, terminated, truncated, is_active) of an unreferenced set -- least recently handed out first --

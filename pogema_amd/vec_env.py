@@ -165,8 +165,24 @@ class VecPogema:
     # ------------------------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_handle", None) is not None and self._handle.value:
+            self._park_buffers()
             self._lib.pgx_destroy(self._handle)
             self._handle = C.c_void_p()
+
+    def _shelf_key(self):
+        return (self.device_index, tuple(self.obs_shape), self.obs_dtype)
+
+    def _park_buffers(self):
+        """reuse_buffers='recycle': zone-spread observation buffers that nobody references any more go to the process-wide
+        shelf (buffers.ParkedBuffers) for the next environment of this shape instead of being unmapped."""
+        rec, pl = getattr(self, "_recycler", None), getattr(self, "placement", None) or {}
+        if rec and str(pl.get("method", "")).startswith("pgx_buffers"):
+            from .buffers import ParkedBuffers
+            try:
+                torch.cuda.current_stream(self.device).synchronize()  # nothing of this engine may still be writing
+                ParkedBuffers.park(self._shelf_key(), rec.retire(), pl)
+            except Exception:
+                pass
 
     def __del__(self):
         try:
@@ -512,7 +528,15 @@ class VecPogema:
         if not self.placement_probe or obs_bytes < self.PLACEMENT_MIN_BYTES:
             bufs = self._plain_obs_buffers(n)  # torch's own memory, XCD shares tuned for launches of >= 2048 envs
         else:
-            bufs = self._pick_obs_buffers(n)   # zone walk, candidates timed, the best n kept
+            from .buffers import ParkedBuffers
+            parked = ParkedBuffers.claim(self._shelf_key(), n)
+            if parked is not None:  # buffers a closed environment of this shape left behind: no walk
+                bufs, info = parked
+                self.placement = dict(info, method="pgx_buffers (two HBM zones per buffer; taken over from a closed environment)")
+                if self.batch >= 2048:
+                    self.placement.update(self.tune_xcd_shares(bufs[0], bufs[-1] if n > 1 else None))
+            else:
+                bufs = self._pick_obs_buffers(n)   # zone walk, candidates timed, the best n kept
         return RecyclingOutputs(bufs, self.batch, self.num_agents)
 
     def _recycled(self, with_obs: bool = True):

@@ -6,6 +6,15 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def empty_shelf():
+    """These tests look at HOW buffers were obtained: no hand-me-downs from environments closed by earlier tests."""
+    from pogema_amd.buffers import ParkedBuffers
+    ParkedBuffers.clear()
+    yield
+    ParkedBuffers.clear()
+
+
 def test_pool_buffers_are_ordinary_device_memory():
     import torch
     from pogema_amd.buffers import ZoneBuffers
@@ -251,3 +260,50 @@ def test_placement_budget_parameter(budget):
         a, b = env.step(acts[t]), ref.step(acts[t])
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     env.close(); ref.close()
+
+
+def test_closed_environments_leave_their_buffers_to_the_next_one(monkeypatch):
+    """buffers.ParkedBuffers: close() parks the zone-spread observation buffers nobody references any more; the next
+    environment with the same observation tensor takes them over without a walk (and without new address space); a
+    buffer the caller still holds is NOT parked; PGX_POOL_CACHE_MB=0 switches the shelf off."""
+    import gc as pygc
+    import torch
+    from pogema_amd import GridConfig, VecPogema, _lib
+    from pogema_amd.buffers import ParkedBuffers
+    lib = _lib.load()
+    cfg = GridConfig(size=32, num_agents=32, obs_radius=5, density=0.3, seed=3, collision_system="soft")
+    B = 3000  # 139 MB per observation tensor -> two output sets from the pool
+    acts = torch.randint(0, 5, (4, B, 32), device="cuda", dtype=torch.int8)
+    ref = VecPogema(cfg, batch=B, auto_reset=True, reuse_buffers=False)
+    ref.reset(seed=3)
+    want = [ref.step(acts[t])[0] for t in range(4)]
+    key = (0, (B, 32, 3, 11, 11), torch.float32)
+
+    a = VecPogema(cfg, batch=B, auto_reset=True)
+    a.reset(seed=3)
+    assert a.placement["method"] == "pgx_buffers (two HBM zones per buffer)" and len(a._recycler) == 2
+    ptrs_a = set(a._recycler.obs_pointers())
+    assert torch.equal(a.step(acts[0])[0], want[0])
+    a.close()
+    pygc.collect()
+    assert len(ParkedBuffers._shelf[key]) == 2
+
+    va = int(lib.pgx_buffers_va_reserved())
+    b = VecPogema(cfg, batch=B, auto_reset=True)
+    b.reset(seed=3)
+    assert "taken over from a closed environment" in b.placement["method"] and key not in ParkedBuffers._shelf
+    assert set(b._recycler.obs_pointers()) == ptrs_a and int(lib.pgx_buffers_va_reserved()) == va
+    for t in range(4):
+        assert torch.equal(b.step(acts[t])[0], want[t])
+    held = b.step(acts[0])[0]  # the caller keeps this one: its buffer must not be parked
+    b.close()
+    assert len(ParkedBuffers._shelf[key]) == 1 and held.data_ptr() not in {t.data_ptr() for t, _ in ParkedBuffers._shelf[key]}
+
+    c = VecPogema(cfg, batch=B, auto_reset=True)  # needs two, one is parked: its own walk
+    c.reset(seed=3)
+    assert c.placement["method"] == "pgx_buffers (two HBM zones per buffer)" and len(ParkedBuffers._shelf[key]) == 1
+    assert held.data_ptr() not in set(c._recycler.obs_pointers())
+    monkeypatch.setenv("PGX_POOL_CACHE_MB", "0")
+    c.close()
+    assert len(ParkedBuffers._shelf[key]) == 1  # switched off: nothing added
+    ref.close()

@@ -8,6 +8,7 @@ released when the last tensor AND the pool object are gone.
 """
 from __future__ import annotations
 
+import atexit
 import collections
 import ctypes as C
 import os
@@ -176,6 +177,9 @@ class ParkedBuffers:
     def clear(cls):
         with cls._lock:
             cls._shelf.clear()
+
+
+atexit.register(ParkedBuffers.clear)  # release parked pools while the HIP runtime is still up, not during module teardown
 
 
 class RecyclingOutputs:

@@ -254,11 +254,12 @@ __device__ __forceinline__ void stream_obs_u8(uint8_t* out, size_t base, int n, 
 // e / W and e / W + 1 (one ds_read2_b32).  `stream_rows16_span` writes the float4s q0, q0 + qs, ... < q1 (index 0 =
 // float offset `head`), keeping (row, col) incrementally; `stream_rows16_edges` the <= 3 + 3 floats in front of / behind
 // the 16-byte aligned part (lanes 0..7 of one wave).
-__device__ __forceinline__ void stream_rows16_span(f32x4_t* out4, const uint32_t* rows32, int head, int W, uint32_t magic,
-                                                   uint32_t spol, int q0, int q1, int qs) {
-    int e0 = head + (q0 << 2);
-    int row = (int)__umulhi((uint32_t)e0, magic);
-    int col = e0 - row * W;
+// store_obs16's policy is a compile-time constant here: with the switch inside the loop every 16-byte store dragged ~25
+// scalar instructions and branches along -- configs[1] 8.3 -> 7.7 us, configs[2] 116.3 -> 115.2, configs[3] 38.75 -> 38.5,
+// configs[4] 421.3 -> 419.0 (in-process A/B on shared buffers, profiles/r3/stream_loop_ab.txt)
+template <int POLICY>
+__device__ __forceinline__ void stream_rows16_loop(f32x4_t* out4, const uint32_t* rows32, int W, int row, int col, int q0, int q1,
+                                                   int qs) {
     const int drow = (4 * qs) / W, dcol = 4 * qs - drow * W;
     for (int q = q0; q < q1; q += qs) {
         const uint32_t w0 = rows32[row >> 1], w1 = rows32[(row >> 1) + 1];
@@ -269,7 +270,7 @@ __device__ __forceinline__ void stream_rows16_span(f32x4_t* out4, const uint32_t
         v.y = (float)((b >> 1) & 1u);
         v.z = (float)((b >> 2) & 1u);
         v.w = (float)((b >> 3) & 1u);
-        store_obs16(&out4[q], v, spol);
+        store_obs16(&out4[q], v, (uint32_t)POLICY);
         col += dcol;
         row += drow;
         if (col >= W) {
@@ -277,6 +278,15 @@ __device__ __forceinline__ void stream_rows16_span(f32x4_t* out4, const uint32_t
             row += 1;
         }
     }
+}
+__device__ __forceinline__ void stream_rows16_span(f32x4_t* out4, const uint32_t* rows32, int head, int W, uint32_t magic,
+                                                   uint32_t spol, int q0, int q1, int qs) {
+    const int e0 = head + (q0 << 2);
+    const int row = (int)__umulhi((uint32_t)e0, magic);
+    const int col = e0 - row * W;
+    if (spol == 0u) stream_rows16_loop<0>(out4, rows32, W, row, col, q0, q1, qs);
+    else if (spol == 1u) stream_rows16_loop<1>(out4, rows32, W, row, col, q0, q1, qs);
+    else stream_rows16_loop<2>(out4, rows32, W, row, col, q0, q1, qs);
 }
 __device__ __forceinline__ void stream_rows16_edges(float* out, const uint16_t* rows16, int n, int head, int tail0, int W,
                                                     uint32_t magic, int t8) {

@@ -21,6 +21,7 @@
 #include <stdint.h>
 
 #include <array>
+#include <type_traits>
 #include <map>
 #include <mutex>
 #include <string>
@@ -706,13 +707,23 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
     float* const obs_out = ROLL ? reinterpret_cast<float*>(reinterpret_cast<char*>(p.obs) + (size_t)slot * (size_t)rp.obs_stride) : p.obs;
 
     if constexpr (P16) {
+        // The window side is a compile-time constant for the radii that matter (W = 11: obs_radius 5, the default and
+        // BASELINE configs[1..3]; 15: configs[4]; 7: configs[0]); other radii run the same code with W at run time.  With W
+        // known the 2 x W LDS reads of an item are issued back to back and waited for once -- before, every row paid its
+        // own LDS round trip, a 16-cycle multiply and two scalar branches, which a lone wave pays in latency.
+        const int W_rt = W, r_rt = r;
+        auto p16_phases = [&](auto wt_tag) {
+        constexpr int WT = decltype(wt_tag)::value;
+        const int W = WT ? WT : W_rt;
+        const int r = WT ? (WT - 1) / 2 : r_rt;
         // ---- phase 3 (P16): row masks -> registers -> (sync) -> packed u16 rows over the dead state -------
         const uint32_t wmask = (1u << W) - 1u;
-        uint32_t rp[3][8];  // 16 rows x 16 bit per item, 3 items per lane (nag * 3 <= 3 * NT)
+        constexpr int RW = WT ? (WT + 1) / 2 : 8;  // words per item: two 16-bit rows each
+        uint32_t rp[3][RW];  // W rows x 16 bit per item, 3 items per lane (nag * 3 <= 3 * NT)
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
 #pragma unroll
-            for (int m = 0; m < 8; ++m) rp[t][m] = 0u;
+            for (int m = 0; m < RW; ++m) rp[t][m] = 0u;
             const int item = tid + t * NT;
             if (item < nag * 3) {
                 const int la = item / 3;
@@ -724,15 +735,42 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
                     const uint32_t* bm = (c == 0 ? s_obst : s_occ) + el * bmw;
                     const int start = y - r;
                     const int w0 = start >> 5, sh = start & 31;
-                    const bool two = (w0 + 1 < wpr);
+                    // Both words of the 64-bit funnel are read unconditionally: when w0 is the last word of the row the
+                    // window ends inside it (sh + W <= 32), so whatever follows in LDS (the next row, the next array)
+                    // never reaches the low W bits.
+                    if constexpr (WT == 0) {  // window side at run time: one row at a time (two words in flight)
 #pragma unroll
-                    for (int wy = 0; wy < 16; ++wy) {
-                        if (wy < W) {
-                            const uint32_t* rowp = bm + (x - r + wy) * wpr + w0;
-                            const uint32_t lo = rowp[0];
-                            const uint32_t hi = two ? rowp[1] : 0u;
-                            const uint32_t bits = (uint32_t)((((uint64_t)hi << 32) | lo) >> sh) & wmask;
-                            rp[t][wy >> 1] |= bits << (16 * (wy & 1));
+                        for (int wy = 0; wy < 16; ++wy) {
+                            if (wy < W) {
+                                const uint32_t* rowp = bm + (x - r + wy) * wpr + w0;
+                                const uint32_t bits = (uint32_t)((((uint64_t)rowp[1] << 32) | rowp[0]) >> sh) & wmask;
+                                rp[t][wy >> 1] |= bits << (16 * (wy & 1));
+                            }
+                        }
+                    } else {
+                    const uint32_t* row0 = bm + (x - r) * wpr + w0;
+                        // RB rows (2 RB LDS words) in flight at a time: more would cost the 8th wave per SIMD its registers
+                        constexpr int RB = WT == 11 ? 6 : WT == 15 ? 5 : 7;
+    #pragma unroll
+                        for (int w8 = 0; w8 < (WT ? WT : 16); w8 += RB) {
+                            uint32_t lo[RB], hi[RB];
+    #pragma unroll
+                            for (int k = 0; k < RB; ++k) {
+                                const int wy = w8 + k;
+                                if (wy < (WT ? WT : 16) && (WT || wy < W)) {
+                                    lo[k] = row0[wy * wpr];
+                                    hi[k] = row0[wy * wpr + 1];
+                                }
+                            }
+    #pragma unroll
+                            for (int k = 0; k < RB; ++k) {
+                                const int wy = w8 + k;
+                                if (wy < (WT ? WT : 16) && (WT || wy < W)) {
+                                    const uint32_t bits = (uint32_t)((((uint64_t)hi[k] << 32) | lo[k]) >> sh) & wmask;
+                                    rp[t][wy >> 1] |= bits << (16 * (wy & 1));
+                                }
+                            }
+                            asm volatile("" ::: "memory");  // keep the next batch of loads behind this batch's use
                         }
                     }
                 } else {
@@ -744,7 +782,7 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
                     const int hit = r - dx;
                     const uint32_t val = (1u << (r - dy)) << (16 * (hit & 1));
 #pragma unroll
-                    for (int m = 0; m < 8; ++m) rp[t][m] = (m == (hit >> 1)) ? val : 0u;
+                    for (int m = 0; m < RW; ++m) rp[t][m] = (m == (hit >> 1)) ? val : 0u;
                 }
             }
         }
@@ -755,8 +793,8 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
             const int item = tid + t * NT;
             if (item < nag * 3) {
 #pragma unroll
-                for (int wy = 0; wy < 16; ++wy)
-                    if (wy < W) rows16[item * W + wy] = (uint16_t)(rp[t][wy >> 1] >> (16 * (wy & 1)));
+                for (int wy = 0; wy < (WT ? WT : 16); ++wy)
+                    if (WT || wy < W) rows16[item * W + wy] = (uint16_t)(rp[t][wy >> 1] >> (16 * (wy & 1)));
             }
         }
         if (tid < 4) rows16[nag * 3 * W + tid] = 0;
@@ -801,6 +839,14 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
             __builtin_amdgcn_s_waitcnt(0);
             p.dbg[(size_t)blk * 4 + 3] = wall_clock64();
         }
+        return;
+        };
+        // (the rollout kernels keep the run-time form: they are at their register limit as it is)
+        if (ROLL) p16_phases(std::integral_constant<int, 0>{});
+        else if (W_rt == 11) p16_phases(std::integral_constant<int, 11>{});
+        else if (W_rt == 15) p16_phases(std::integral_constant<int, 15>{});
+        else if (W_rt == 7) p16_phases(std::integral_constant<int, 7>{});
+        else p16_phases(std::integral_constant<int, 0>{});
         return;
     }
 

@@ -258,36 +258,65 @@ __device__ __forceinline__ void stream_obs_u8(uint8_t* out, size_t base, int n, 
 // store_obs16's policy is a compile-time constant here: with the switch inside the loop every 16-byte store dragged ~25
 // scalar instructions and branches along -- configs[1] 8.3 -> 7.7 us, configs[2] 116.3 -> 115.2, configs[3] 38.75 -> 38.5,
 // configs[4] 421.3 -> 419.0 (in-process A/B on shared buffers, profiles/r3/stream_loop_ab.txt)
-template <int POLICY>
+template <int POLICY, bool PIPE>
 __device__ __forceinline__ void stream_rows16_loop(f32x4_t* out4, const uint32_t* rows32, int W, int row, int col, int q0, int q1,
-                                                   int qs) {
+                                                   int qs, int last_word) {
     const int drow = (4 * qs) / W, dcol = 4 * qs - drow * W;
-    for (int q = q0; q < q1; q += qs) {
-        const uint32_t w0 = rows32[row >> 1], w1 = rows32[(row >> 1) + 1];
-        const uint32_t pair = (uint32_t)((((uint64_t)w1 << 32) | w0) >> (16 * (row & 1)));  // row | row+1 << 16
-        const uint32_t b = ((pair & 0xFFFFu) >> col) | ((pair >> 16) << (W - col));
-        f32x4_t v;
-        v.x = (float)(b & 1u);
-        v.y = (float)((b >> 1) & 1u);
-        v.z = (float)((b >> 2) & 1u);
-        v.w = (float)((b >> 3) & 1u);
-        store_obs16(&out4[q], v, (uint32_t)POLICY);
-        col += dcol;
-        row += drow;
-        if (col >= W) {
-            col -= W;
-            row += 1;
+    if constexpr (PIPE) {
+        // software pipeline: the row words of iteration k+1 are read from LDS while iteration k is converted and stored
+        // (the compiler does not do it: one exposed LDS round trip per 1-KiB store otherwise; configs[2] 113.8 -> 112.9 us,
+        // profiles/r3/stream_loop_ab.txt); the read past the last iteration is clamped to the zero pad behind the rows
+        uint32_t w0 = rows32[row >> 1], w1 = rows32[(row >> 1) + 1];
+        for (int q = q0; q < q1; q += qs) {
+            int ncol = col + dcol, nrow = row + drow;
+            if (ncol >= W) {
+                ncol -= W;
+                nrow += 1;
+            }
+            const int nw = min(nrow >> 1, last_word);
+            const uint32_t n0 = rows32[nw], n1 = rows32[nw + 1];
+            const uint32_t pair = (uint32_t)((((uint64_t)w1 << 32) | w0) >> (16 * (row & 1)));  // row | row+1 << 16
+            const uint32_t b = ((pair & 0xFFFFu) >> col) | ((pair >> 16) << (W - col));
+            f32x4_t v;
+            v.x = (float)(b & 1u);
+            v.y = (float)((b >> 1) & 1u);
+            v.z = (float)((b >> 2) & 1u);
+            v.w = (float)((b >> 3) & 1u);
+            store_obs16(&out4[q], v, (uint32_t)POLICY);
+            w0 = n0;
+            w1 = n1;
+            row = nrow;
+            col = ncol;
+        }
+    } else {  // the rollout kernels sit at their register limit: four live values fewer
+        for (int q = q0; q < q1; q += qs) {
+            const uint32_t w0 = rows32[row >> 1], w1 = rows32[(row >> 1) + 1];
+            const uint32_t pair = (uint32_t)((((uint64_t)w1 << 32) | w0) >> (16 * (row & 1)));
+            const uint32_t b = ((pair & 0xFFFFu) >> col) | ((pair >> 16) << (W - col));
+            f32x4_t v;
+            v.x = (float)(b & 1u);
+            v.y = (float)((b >> 1) & 1u);
+            v.z = (float)((b >> 2) & 1u);
+            v.w = (float)((b >> 3) & 1u);
+            store_obs16(&out4[q], v, (uint32_t)POLICY);
+            col += dcol;
+            row += drow;
+            if (col >= W) {
+                col -= W;
+                row += 1;
+            }
         }
     }
 }
+template <bool PIPE>
 __device__ __forceinline__ void stream_rows16_span(f32x4_t* out4, const uint32_t* rows32, int head, int W, uint32_t magic,
-                                                   uint32_t spol, int q0, int q1, int qs) {
+                                                   uint32_t spol, int q0, int q1, int qs, int last_word) {
     const int e0 = head + (q0 << 2);
     const int row = (int)__umulhi((uint32_t)e0, magic);
     const int col = e0 - row * W;
-    if (spol == 0u) stream_rows16_loop<0>(out4, rows32, W, row, col, q0, q1, qs);
-    else if (spol == 1u) stream_rows16_loop<1>(out4, rows32, W, row, col, q0, q1, qs);
-    else stream_rows16_loop<2>(out4, rows32, W, row, col, q0, q1, qs);
+    if (spol == 0u) stream_rows16_loop<0, PIPE>(out4, rows32, W, row, col, q0, q1, qs, last_word);
+    else if (spol == 1u) stream_rows16_loop<1, PIPE>(out4, rows32, W, row, col, q0, q1, qs, last_word);
+    else stream_rows16_loop<2, PIPE>(out4, rows32, W, row, col, q0, q1, qs, last_word);
 }
 __device__ __forceinline__ void stream_rows16_edges(float* out, const uint16_t* rows16, int n, int head, int tail0, int W,
                                                     uint32_t magic, int t8) {
@@ -832,8 +861,8 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
         const bool span = MW && !(p.flags & 512u);
         const int part = (nvec + nw - 1) / nw;
         const int q0 = span ? wave * part + lane : tid, q1 = span ? min(nvec, (wave + 1) * part) : nvec;
-        stream_rows16_span(reinterpret_cast<f32x4_t*>(out + head), reinterpret_cast<const uint32_t*>(rows16), head, W, magic,
-                           (uint32_t)p.store_policy, q0, q1, span ? 64 : NT);
+        stream_rows16_span<!ROLL>(reinterpret_cast<f32x4_t*>(out + head), reinterpret_cast<const uint32_t*>(rows16), head, W, magic,
+                           (uint32_t)p.store_policy, q0, q1, span ? 64 : NT, (nag * 3 * W) >> 1);
         if (when_stores == 2) emit_state(pos, tgt, active, elapsed, macc, so);
         if (dbg && !dbg2 && tid == 0) {
             __builtin_amdgcn_s_waitcnt(0);

@@ -594,6 +594,7 @@ static void fill_params(const pgx_env* e, pgx::StepParams& p) {
     p.map_w = c.width;
     p.map_cells = c.height * c.width;
     p.w_magic = (uint32_t)((1ull << 32) / (uint64_t)e->W) + 1u;
+    p.a_magic = c.num_agents > 1 ? (uint32_t)((1ull << 32) / (uint64_t)c.num_agents) + 1u : 0u;  // 0: A = 1, slot = env
     p.collision = c.collision_system;
     p.on_target = c.on_target;
     p.max_steps = c.max_episode_steps;

@@ -61,6 +61,7 @@ struct StepParams {
     int32_t map_w;     // unpadded width
     int32_t map_cells; // unpadded H * W
     uint32_t w_magic;  // ceil(2^32 / (2r+1)): exact division of flat window offsets by the window side
+    uint32_t a_magic;  // ceil(2^32 / num_agents): agent slot -> environment of the wave (slots < 4096)
     // behaviour
     int32_t mode, collision, on_target, max_steps, auto_reset, action_dtype;
     int32_t epw;       // environments per wave (single-wave blocks, num_agents <= 64)

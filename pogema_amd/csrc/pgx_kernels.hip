@@ -757,7 +757,7 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
             if (item < nag * 3) {
                 const int la = item / 3;
                 const int c = item - la * 3;
-                const int el = MW ? 0 : (la / A);
+                const int el = MW ? 0 : (p.a_magic ? (int)__umulhi((uint32_t)la, p.a_magic) : la);  // la / A (la < 4096)
                 const uint32_t cell = s_apos[la];
                 const int x = (int)(cell >> 16), y = (int)(cell & 0xFFFFu);
                 if (c < 2) {
@@ -885,7 +885,7 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
         for (int item = tid; item < nag * 3; item += NT) {
             const int la = item / 3;
             const int c = item - la * 3;
-            const int el = MW ? 0 : (la / A);
+            const int el = MW ? 0 : (p.a_magic ? (int)__umulhi((uint32_t)la, p.a_magic) : la);  // la / A
             const uint32_t cell = s_apos[la];
             const int x = (int)(cell >> 16), y = (int)(cell & 0xFFFFu);
             uint32_t* out = s_rows + item * W;

@@ -948,18 +948,24 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
         const int part = (nvec + nw - 1) / nw;
         const int q0 = span ? wave * part + lane : tid, q1 = span ? min(nvec, (wave + 1) * part) : nvec;
         const int qs = span ? 64 : NT;
-        for (int q = q0; q < q1; q += qs) {
-            const int e0 = head + (q << 2);
-            const int row = (int)__umulhi((uint32_t)e0, magic);
-            const int col = e0 - row * W;
-            const uint32_t b = (s_rows[row] >> col) | (s_rows[row + 1] << (W - col));
-            f32x4 v;
-            v.x = (float)(b & 1u);
-            v.y = (float)((b >> 1) & 1u);
-            v.z = (float)((b >> 2) & 1u);
-            v.w = (float)((b >> 3) & 1u);
-            store_obs16(reinterpret_cast<f32x4_t*>(&out4[q]), v, (uint32_t)p.store_policy);
-        }
+        auto stream32 = [&](auto policy_tag) {  // the store policy as a compile-time constant, as in stream_rows16_loop
+            constexpr uint32_t POLICY = decltype(policy_tag)::value;
+            for (int q = q0; q < q1; q += qs) {
+                const int e0 = head + (q << 2);
+                const int row = (int)__umulhi((uint32_t)e0, magic);
+                const int col = e0 - row * W;
+                const uint32_t b = (s_rows[row] >> col) | (s_rows[row + 1] << (W - col));
+                f32x4 v;
+                v.x = (float)(b & 1u);
+                v.y = (float)((b >> 1) & 1u);
+                v.z = (float)((b >> 2) & 1u);
+                v.w = (float)((b >> 3) & 1u);
+                store_obs16(reinterpret_cast<f32x4_t*>(&out4[q]), v, POLICY);
+            }
+        };
+        if (p.store_policy == 0) stream32(std::integral_constant<uint32_t, 0u>{});
+        else if (p.store_policy == 1) stream32(std::integral_constant<uint32_t, 1u>{});
+        else stream32(std::integral_constant<uint32_t, 2u>{});
         if (when_stores == 2) emit_state(pos, tgt, active, elapsed, macc, so);
         if (dbg && !dbg2 && tid == 0) {
             __builtin_amdgcn_s_waitcnt(0);  // stores retired (vmcnt 0) before the end stamp

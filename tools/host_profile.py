@@ -1,5 +1,7 @@
+"""Diagnostic (round 3): where the host time of one VecPogema.step() goes (per-component microbenchmarks + cProfile), on a
+small environment whose kernel is shorter than the Python call.  usage: python tools/host_profile.py"""
 import os, sys, time, cProfile, pstats
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pogema_amd import GridConfig, VecPogema
 gc = GridConfig(size=16, num_agents=8, obs_radius=5, density=0.3, seed=0, collision_system="soft")

@@ -234,20 +234,24 @@ __device__ __forceinline__ void stream_obs_u8(uint8_t* out, size_t base, int n, 
     const int part = (nvec + nw - 1) / nw;
     const int q0 = nw > 1 ? wave * part + (tid & 63) : tid, q1 = nw > 1 ? min(nvec, (wave + 1) * part) : nvec;
     const int qs = nw > 1 ? 64 : NT;
-    for (int q = q0; q < q1; q += qs) {
-        const int e0 = head + (q << 4);
-        int row = (int)__umulhi((uint32_t)e0, magic);
-        const int col = e0 - row * W;
-        uint32_t m = row_bits(row) >> col;
-        for (int have = W - col; have < 16; have += W) m |= row_bits(++row) << have;
-        u32x4 v;
-        v.x = ((m & 15u) * 0x204081u) & 0x01010101u;
-        v.y = (((m >> 4) & 15u) * 0x204081u) & 0x01010101u;
-        v.z = (((m >> 8) & 15u) * 0x204081u) & 0x01010101u;
-        v.w = (((m >> 12) & 15u) * 0x204081u) & 0x01010101u;
-        if (nontemporal) __builtin_nontemporal_store(v, &out4[q]);
-        else out4[q] = v;
-    }
+    auto loop = [&](auto nt_tag) {  // the store flavour as a compile-time constant (no branch inside the loop)
+        for (int q = q0; q < q1; q += qs) {
+            const int e0 = head + (q << 4);
+            int row = (int)__umulhi((uint32_t)e0, magic);
+            const int col = e0 - row * W;
+            uint32_t m = row_bits(row) >> col;
+            for (int have = W - col; have < 16; have += W) m |= row_bits(++row) << have;
+            u32x4 v;
+            v.x = ((m & 15u) * 0x204081u) & 0x01010101u;
+            v.y = (((m >> 4) & 15u) * 0x204081u) & 0x01010101u;
+            v.z = (((m >> 8) & 15u) * 0x204081u) & 0x01010101u;
+            v.w = (((m >> 12) & 15u) * 0x204081u) & 0x01010101u;
+            if constexpr (decltype(nt_tag)::value) __builtin_nontemporal_store(v, &out4[q]);
+            else out4[q] = v;
+        }
+    };
+    if (nontemporal) loop(std::true_type{});
+    else loop(std::false_type{});
 }
 
 // ---- P16 float32 stream (window side <= 16): the slice's (agent, channel, window row) masks sit in LDS as packed u16

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PGX_ABI_VERSION 3
+#define PGX_ABI_VERSION 4
 
 /* error codes */
 #define PGX_OK 0
@@ -59,6 +59,11 @@ extern "C" {
 #define PGX_SOFT_ALL_STAY 1          /* Q1 alternative: every claimant of a contested cell stays (textbook MAPF)       */
 #define PGX_COOP_REWARD_ALL_SOLVED 0 /* Q4: on_target = NOTHING pays 1.0 to every agent iff ALL are on their goals    */
 #define PGX_COOP_REWARD_PER_AGENT 1  /* Q4 alternative: 1.0 to each agent standing on its own goal in this step        */
+#define PGX_SOFT_OCCUPANCY_EXACT 0       /* Q2: after a `soft` step the occupancy array (`Grid.positions`, the `agents` plane of
+                                           the observations) is exactly the set of visible agents' cells              */
+#define PGX_SOFT_OCCUPANCY_INDEX_ORDER 1 /* Q2 alternative: the literal `Grid.move_without_checks` loop as recalled -- clear the
+                                           old cell, set the new one, agent by agent in index order: an agent entering the
+                                           cell a HIGHER-index agent is leaving is missing from this step's `agents` planes */
 #define PGX_BAD_ACTION_NOOP 0        /* Q7: an action outside 0..4 is a noop                                           */
 #define PGX_BAD_ACTION_FLAG 1        /* Q7 alternative: still a noop on the device, but counted -- pgx_bad_action_count()
                                         lets the host raise the reference's IndexError                               */
@@ -115,6 +120,8 @@ typedef struct pgx_config {
     int32_t coop_reward;       /* PGX_COOP_REWARD_* (0 = recalled)                                       */
     int32_t bad_action;        /* PGX_BAD_ACTION_*  (0 = noop)                                           */
     int32_t lifelong_rng;      /* PGX_LIFELONG_RNG_* (0 = the build's counter-based stream)              */
+    int32_t soft_occupancy;    /* PGX_SOFT_OCCUPANCY_* (0 = occupancy == cells of the visible agents)    */
+    int32_t reserved0;         /* must be 0                                                              */
 } pgx_config;
 
 typedef struct pgx_env pgx_env; /* opaque */

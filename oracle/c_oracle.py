@@ -16,6 +16,7 @@ ON_TARGET = {"finish": 0, "restart": 1, "nothing": 2}
 SOFT_VERTEX_RULE = {"lowest_index": 0, "all_stay": 1}
 COOP_REWARD = {"all_solved": 0, "per_agent": 1}
 BAD_ACTION = {"noop": 0, "flag": 1}
+SOFT_OCCUPANCY = {"exact": 0, "index_order": 1}
 
 
 class PoConfig(C.Structure):
@@ -24,7 +25,7 @@ class PoConfig(C.Structure):
                 ("max_episode_steps", C.c_int32), ("auto_reset", C.c_int32), ("reserved0", C.c_int32),
                 ("seed", C.c_uint64), ("env_index_base", C.c_int64), ("random_outside", C.c_int32),
                 ("outside_density", C.c_float), ("soft_vertex_rule", C.c_int32), ("coop_reward", C.c_int32),
-                ("bad_action", C.c_int32), ("reserved1", C.c_int32)]
+                ("bad_action", C.c_int32), ("soft_occupancy", C.c_int32)]
 
 
 _lib = None
@@ -59,7 +60,7 @@ class COracle:
     def __init__(self, batch, height, width, num_agents, obs_radius, collision_system="priority", on_target="finish",
                  max_episode_steps=64, auto_reset=False, seed=0, env_index_base=0, empty_outside=True,
                  outside_density=0.0, soft_vertex_rule="lowest_index", coop_reward="all_solved", bad_action="noop",
-                 lifelong_rng="build"):
+                 lifelong_rng="build", soft_occupancy="exact"):
         if lifelong_rng != "build":
             raise NotImplementedError("the plain-C port has the build's lifelong stream only; use the Python oracle")
         self.lib = load()
@@ -68,7 +69,7 @@ class COracle:
         cfg = PoConfig(batch, height, width, num_agents, obs_radius, COLLISION[collision_system], ON_TARGET[on_target],
                        max_episode_steps, int(auto_reset), 0, seed, env_index_base, 0 if empty_outside else 1,
                        float(outside_density), SOFT_VERTEX_RULE[soft_vertex_rule], COOP_REWARD[coop_reward],
-                       BAD_ACTION[bad_action], 0)
+                       BAD_ACTION[bad_action], SOFT_OCCUPANCY[soft_occupancy])
         self.h = self.lib.po_create(C.byref(cfg))
         if not self.h:
             raise MemoryError("po_create failed")

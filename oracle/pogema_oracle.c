@@ -35,7 +35,8 @@ typedef struct po_config {
     int32_t soft_vertex_rule; /* 0 lowest index wins a contested cell (literal remove + reverse loop), 1 all claimants stay */
     int32_t coop_reward;      /* 0 1.0 to all iff all on goal, 1 1.0 to each agent on its own goal */
     int32_t bad_action;       /* 0 out-of-range action = noop, 1 noop + counted (po_bad_action_count) */
-    int32_t reserved1;
+    int32_t soft_occupancy;   /* docs/SPEC.md Q2: 0 occupancy == cells of the visible agents; 1 the literal per-agent
+                                 move_without_checks loop (clear old, set new, in index order) as recalled */
 } po_config;
 
 typedef struct po_env {
@@ -298,13 +299,34 @@ static void revert_action(po_env* e, int b, scratch* s, int agent, int cell) {
     }
 }
 
+/* Grid.move_without_checks for every active agent once the surviving `soft` moves are known (docs/SPEC.md Q2).
+ * soft_occupancy 0: the occupancy array afterwards is exactly the set of active agents' cells; 1: the literal loop as
+ * recalled -- clear the old cell, set the new one, agent by agent in index order (an agent entering the cell a HIGHER-index
+ * agent is leaving has its new cell cleared again by that agent's turn). */
+static void apply_soft_moves(po_env* e, int b, const int8_t* acts) {
+    const int A = e->c.num_agents, PW = e->PW;
+    const size_t base = (size_t)b * A;
+    uint8_t* occ = e->occ + (size_t)b * e->PH * e->PW;
+    if (e->c.soft_occupancy == 0) {
+        for (int i = 0; i < A; ++i)
+            if (e->active[base + i]) occ[(size_t)e->px[base + i] * PW + e->py[base + i]] = 0;
+    }
+    for (int i = 0; i < A; ++i) {
+        if (!e->active[base + i]) continue;
+        const int a = acts[i];
+        if (e->c.soft_occupancy != 0) occ[(size_t)e->px[base + i] * PW + e->py[base + i]] = 0;
+        e->px[base + i] += MOVE_DX[a];
+        e->py[base + i] += MOVE_DY[a];
+        occ[(size_t)e->px[base + i] * PW + e->py[base + i]] = 1;
+    }
+}
+
 /* Pogema.move_agents */
 static void move_agents(po_env* e, int b, const int64_t* actions, scratch* s) {
     const int A = e->c.num_agents, PW = e->PW;
     const size_t base = (size_t)b * A;
     const size_t P = (size_t)e->PH * e->PW;
     const uint8_t* o = e->obst + (size_t)b * P;
-    uint8_t* occ = e->occ + (size_t)b * P;
     if (e->c.collision_system == 0) {
         for (int i = 0; i < A; ++i)
             if (e->active[base + i]) grid_move(e, b, i, (int)actions[i]);
@@ -362,18 +384,8 @@ static void move_agents(po_env* e, int b, const int64_t* actions, scratch* s) {
             for (int k = 0; k < s->ntouched; ++k) s->ccnt[s->touched[k]] = 0;
         }
         for (int i = 0; i < A; ++i)
-            if (e->active[base + i]) {
-                const int c = e->px[base + i] * PW + e->py[base + i];
-                s->who[c] = -1;
-                occ[c] = 0;
-            }
-        for (int i = 0; i < A; ++i) {
-            if (!e->active[base + i]) continue;
-            const int a = s->acts[i];
-            e->px[base + i] += MOVE_DX[a];
-            e->py[base + i] += MOVE_DY[a];
-            occ[(size_t)e->px[base + i] * PW + e->py[base + i]] = 1;
-        }
+            if (e->active[base + i]) s->who[e->px[base + i] * PW + e->py[base + i]] = -1;
+        apply_soft_moves(e, b, s->acts);
     } else {
         s->ntouched = 0;
         for (int i = 0; i < A; ++i) s->acts[i] = (int8_t)actions[i];
@@ -407,15 +419,7 @@ static void move_agents(po_env* e, int b, const int64_t* actions, scratch* s) {
             const int d = (x + MOVE_DX[a]) * PW + (y + MOVE_DY[a]);
             if (s->ccnt[d] > 1 || o[d]) revert_action(e, b, s, i, d);
         }
-        for (int i = 0; i < A; ++i)
-            if (e->active[base + i]) occ[(size_t)e->px[base + i] * PW + e->py[base + i]] = 0;
-        for (int i = 0; i < A; ++i) {
-            if (!e->active[base + i]) continue;
-            const int a = s->acts[i];
-            e->px[base + i] += MOVE_DX[a];
-            e->py[base + i] += MOVE_DY[a];
-            occ[(size_t)e->px[base + i] * PW + e->py[base + i]] = 1;
-        }
+        apply_soft_moves(e, b, s->acts);
         for (int k = 0; k < s->ntouched; ++k) {
             const int c = s->touched[k];
             s->ccnt[c] = 0;

@@ -196,11 +196,13 @@ class PogemaOracle:
 
     def __init__(self, obstacles, agents_xy, targets_xy, obs_radius=5, collision_system="priority",
                  on_target="finish", max_episode_steps=64, auto_reset=False, seed=0, env_index=0,
-                 empty_outside=True, outside_density=0.0, epoch=0, soft_vertex_rule="lowest_index",
+                 empty_outside=True, outside_density=0.0, epoch=0, soft_vertex_rule="lowest_index", soft_occupancy="exact",
                  coop_reward="all_solved", bad_action="noop", lifelong_rng="build"):
         assert collision_system in COLLISION_SYSTEMS and on_target in ON_TARGET
         assert soft_vertex_rule in SOFT_VERTEX_RULES and coop_reward in COOP_REWARDS and bad_action in BAD_ACTIONS
         self.soft_vertex_rule, self.coop_reward, self.bad_action = soft_vertex_rule, coop_reward, bad_action
+        assert soft_occupancy in ("exact", "index_order")
+        self.soft_occupancy = soft_occupancy
         assert lifelong_rng in ("build", "numpy")
         self.lifelong_rng = lifelong_rng
         self._init_args = (np.array(obstacles, copy=True), [tuple(map(int, p)) for p in agents_xy],
@@ -314,16 +316,7 @@ class PogemaOracle:
                 for i in revert:
                     actions[i] = 0
                     changed = True
-            for i in range(n):
-                if g.is_active[i]:
-                    x, y = g.positions_xy[i]
-                    g.positions[x, y] = FREE
-            for i in range(n):
-                if g.is_active[i]:
-                    x, y = g.positions_xy[i]
-                    dx, dy = MOVES[actions[i]]
-                    g.positions_xy[i] = (x + dx, y + dy)
-                    g.positions[x + dx, y + dy] = OBSTACLE
+            self._apply_soft_moves(actions)
         else:  # soft, recalled literal algorithm (lowest index wins a contested cell)
             actions = list(actions)
             used_cells = {}
@@ -349,19 +342,36 @@ class PogemaOracle:
                     dx, dy = MOVES[actions[i]]
                     if len(used_cells[x + dx, y + dy]) > 1 or g.has_obstacle(x + dx, y + dy):
                         self._revert_action(i, used_cells, (x + dx, y + dy), actions)
-            # move_without_checks: the surviving moves are mutually compatible, so the occupancy
-            # array afterwards is exactly the set of active agents' cells (DESIGN.md open
-            # question 2: upstream's per-agent clear/set order is not recalled with confidence).
-            for i in range(n):
-                if g.is_active[i]:
-                    x, y = g.positions_xy[i]
-                    g.positions[x, y] = FREE
+            self._apply_soft_moves(actions)
+
+    def _apply_soft_moves(self, actions):
+        """`move_without_checks` for every active agent (the surviving moves are mutually compatible).  docs/SPEC.md Q2:
+        'exact' (default): the occupancy array afterwards is exactly the set of active agents' cells; 'index_order': the
+        literal per-agent loop as recalled -- clear the old cell, set the new one, agent by agent in index order -- in which
+        an agent that enters the cell a HIGHER-index agent is leaving has its new cell cleared again by that agent's
+        turn: it stands there but is missing from the occupancy array (and from everybody's `agents` plane) until its
+        next turn re-sets it."""
+        g = self.grid
+        n = self.num_agents
+        if self.soft_occupancy == "index_order":
             for i in range(n):
                 if g.is_active[i]:
                     x, y = g.positions_xy[i]
                     dx, dy = MOVES[actions[i]]
-                    g.positions_xy[i] = (x + dx, y + dy)
+                    g.positions[x, y] = FREE
                     g.positions[x + dx, y + dy] = OBSTACLE
+                    g.positions_xy[i] = (x + dx, y + dy)
+            return
+        for i in range(n):
+            if g.is_active[i]:
+                x, y = g.positions_xy[i]
+                g.positions[x, y] = FREE
+        for i in range(n):
+            if g.is_active[i]:
+                x, y = g.positions_xy[i]
+                dx, dy = MOVES[actions[i]]
+                g.positions_xy[i] = (x + dx, y + dy)
+                g.positions[x + dx, y + dy] = OBSTACLE
 
     # -- A6 / A7 / A8 + A13 + auto-reset ---------------------------------------------------------
     def step(self, actions):

@@ -12,12 +12,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PGX_LIB: diagnostic override (A/B of two builds of the SAME engine on one box); never a fallback
 LIB_PATH = os.environ.get("PGX_LIB") or os.path.join(_HERE, "libpogema_amd.so")
 
-PGX_ABI_VERSION = 3
+PGX_ABI_VERSION = 4
 
 COLLISION_SYSTEMS = {"priority": 0, "block_both": 1, "soft": 2}
 ON_TARGET = {"finish": 0, "restart": 1, "nothing": 2}
 ACTION_DTYPES = {"int8": 0, "int32": 1, "int64": 2}
 SOFT_VERTEX_RULES = {"lowest_index": 0, "all_stay": 1}
+SOFT_OCCUPANCY = {"exact": 0, "index_order": 1}
 COOP_REWARDS = {"all_solved": 0, "per_agent": 1}
 BAD_ACTIONS = {"noop": 0, "flag": 1}
 LIFELONG_RNGS = {"build": 0, "numpy": 1}
@@ -82,6 +83,7 @@ class PgxConfig(C.Structure):
         ("seed", C.c_uint64), ("env_index_base", C.c_int64),
         ("random_outside", C.c_int32), ("outside_density", C.c_float),
         ("soft_vertex_rule", C.c_int32), ("coop_reward", C.c_int32), ("bad_action", C.c_int32), ("lifelong_rng", C.c_int32),
+        ("soft_occupancy", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

@@ -146,9 +146,10 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
     if (cfg->random_outside && !(cfg->outside_density >= 0.0f && cfg->outside_density <= 1.0f))
         return fail(PGX_E_INVALID, "outside_density %.3f outside [0, 1]", (double)cfg->outside_density);
     if (cfg->soft_vertex_rule < 0 || cfg->soft_vertex_rule > 1 || cfg->coop_reward < 0 || cfg->coop_reward > 1 ||
-        cfg->bad_action < 0 || cfg->bad_action > 1 || cfg->lifelong_rng < 0 || cfg->lifelong_rng > 1)
-        return fail(PGX_E_INVALID, "unknown semantics switch (soft_vertex_rule %d, coop_reward %d, bad_action %d)",
-                    cfg->soft_vertex_rule, cfg->coop_reward, cfg->bad_action);
+        cfg->bad_action < 0 || cfg->bad_action > 1 || cfg->lifelong_rng < 0 || cfg->lifelong_rng > 1 ||
+        cfg->soft_occupancy < 0 || cfg->soft_occupancy > 1 || cfg->reserved0 != 0)
+        return fail(PGX_E_INVALID, "unknown semantics switch (soft_vertex_rule %d, coop_reward %d, bad_action %d, soft_occupancy %d)",
+                    cfg->soft_vertex_rule, cfg->coop_reward, cfg->bad_action, cfg->soft_occupancy);
     if (cfg->obs_dtype != PGX_OBS_F32 && cfg->obs_dtype != PGX_OBS_U8)
         return fail(PGX_E_INVALID, "unknown obs_dtype %d", cfg->obs_dtype);
     if ((int64_t)cfg->num_agents > (int64_t)cfg->height * cfg->width)
@@ -610,6 +611,7 @@ static void fill_params(const pgx_env* e, pgx::StepParams& p) {
     }
     p.obs_u8 = e->cfg.obs_dtype == PGX_OBS_U8 ? 1 : 0;
     p.soft_rule = c.soft_vertex_rule;
+    p.soft_occupancy = c.soft_occupancy;
     p.coop_reward = c.coop_reward;
     p.bad_action = c.bad_action;
     p.bad_count = e->bad_count;

@@ -70,6 +70,7 @@ struct StepParams {
     int32_t store_policy;  // observation stores: 0 plain, 1 nontemporal, 2 sc1 write-through (StepGeometry::store_policy)
     int32_t state_stores;  // when the small per-step result stores are issued: 0 at once, 1 after the LDS barrier, 2 after the stream
     int32_t soft_rule;    // PGX_SOFT_*  (docs/SPEC.md Q1)
+    int32_t soft_occupancy;  // PGX_SOFT_OCCUPANCY_* (Q2)
     int32_t coop_reward;  // PGX_COOP_REWARD_* (Q4)
     int32_t bad_action;   // PGX_BAD_ACTION_* (Q7)
     int32_t xcd_n[8];     // workgroups (= environment slices) given to each XCD, proportional to its measured store rate

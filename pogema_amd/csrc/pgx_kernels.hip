@@ -555,6 +555,10 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
         }
         uint32_t cur = to_c22(pos);                     // 22-bit key of the own cell
         uint32_t vis = active ? cur : NOCELL_A;         // ... as seen by others (hidden agents stand nowhere)
+        // docs/SPEC.md Q2, PGX_SOFT_OCCUPANCY_INDEX_ORDER: upstream's per-agent clear-old / set-new loop in index order
+        // leaves an agent that entered the cell a HIGHER-index agent is leaving out of the occupancy array (that agent's
+        // turn clears the cell again) -- closed form of the literal loop: moved && occupant-of-destination index > own
+        bool ghost = false;
 
         if (p.mode == MODE_STEP) {
             // ================= move + collision resolve =========================================
@@ -652,6 +656,7 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
                 cur = want;
                 vis = want;
                 pos = from_c22(want);
+                ghost = p.soft_occupancy != 0 && p.collision == COLLISION_SOFT && okey < 1024u && (int)okey > i;
             }
 
             // ================= goals, rewards, done flags ==========
@@ -716,6 +721,7 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
                 active = true;
                 vis = to_c22(pos);
             }
+            if (so.do_reset) ghost = false;
             if (!late_stores) emit_state(pos, tgt, active, elapsed, macc, so);
         }
 
@@ -724,7 +730,7 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
             const int la = MW ? tid : (env_l * A + alane);
             s_apos[la] = pos;
             s_atgt[la] = tgt;
-            if (vis != NOCELL_A) {
+            if (vis != NOCELL_A && !ghost) {
                 const uint32_t x = pos >> 16, y = pos & 0xFFFFu;
                 atomicOr(&s_occ[env_l * bmw + x * wpr + (y >> 5)], 1u << (y & 31));
             }

@@ -1,6 +1,6 @@
 """Switches for the semantics of the reference that the builder recalls with LOW confidence.
 
-The reference source is not mounted (/root/reference/README.md:3,5 -- "code is hosted elsewhere"), so three details
+The reference source is not mounted (/root/reference/README.md:3,5 -- "code is hosted elsewhere"), so a few details
 of upstream `pogema/envs.py` are recollections that the real package may contradict (docs/SPEC.md open questions
 Q1, Q4, Q7).  Each is a configuration switch -- implemented in the step kernel, in both oracles and in the parity
 matrix -- so that pinning against the real package is a flip here, not a kernel edit:
@@ -10,6 +10,12 @@ matrix -- so that pinning against the real package is a flip here, not a kernel 
                                  + reverse-index loop + recursive `_revert_action`, as recalled);
                   'all_stay'   : every claimant of a contested cell stays (the textbook MAPF vertex-conflict rule,
                                  SURVEY.md A5's one-line "net semantics").
+    soft_occupancy 'exact' (default): after a `soft` step the occupancy array (`Grid.positions`, the `agents` plane of every
+                                 observation) is exactly the set of visible agents' cells;
+                  'index_order': the literal `move_without_checks` loop as recalled (Q2) -- clear the old cell, set the new
+                                 one, agent by agent in index order: an agent that enters the cell a HIGHER-index agent
+                                 is leaving gets its new cell cleared again by that agent's turn and is missing from
+                                 the `agents` planes of this step's observations (its next turn re-sets it).
     coop_reward   'all_solved' (default): on_target='nothing' pays 1.0 to every agent iff ALL agents stand on their
                                  goals (`is_task_solved`);
                   'per_agent'  : 1.0 to each agent standing on its own goal in this step.
@@ -43,6 +49,7 @@ from dataclasses import dataclass
 
 LIFELONG_RNG = ("build", "numpy")
 SOFT_VERTEX = ("lowest_index", "all_stay")
+SOFT_OCCUPANCY = ("exact", "index_order")
 COOP_REWARD = ("all_solved", "per_agent")
 BAD_ACTION = ("noop", "flag")
 GENERATOR_RNG = ("build", "numpy")
@@ -51,13 +58,14 @@ GENERATOR_RNG = ("build", "numpy")
 @dataclass(frozen=True)
 class Semantics:
     soft_vertex: str = "lowest_index"
+    soft_occupancy: str = "exact"
     coop_reward: str = "all_solved"
     bad_action: str = "noop"
     lifelong_rng: str = "build"
     generator_rng: str = "build"
 
     def __post_init__(self):
-        for name, allowed in (("soft_vertex", SOFT_VERTEX), ("coop_reward", COOP_REWARD), ("bad_action", BAD_ACTION),
+        for name, allowed in (("soft_vertex", SOFT_VERTEX), ("soft_occupancy", SOFT_OCCUPANCY), ("coop_reward", COOP_REWARD), ("bad_action", BAD_ACTION),
                               ("lifelong_rng", LIFELONG_RNG), ("generator_rng", GENERATOR_RNG)):
             if getattr(self, name) not in allowed:
                 raise ValueError(f"Semantics.{name} must be one of {allowed}, got {getattr(self, name)!r}")
@@ -71,12 +79,12 @@ class Semantics:
             if "=" not in item:
                 raise ValueError(f"PGX_SEMANTICS entry {item!r} is not key=value")
             k, v = item.split("=", 1)
-            if k not in ("soft_vertex", "coop_reward", "bad_action", "lifelong_rng", "generator_rng"):
+            if k not in ("soft_vertex", "soft_occupancy", "coop_reward", "bad_action", "lifelong_rng", "generator_rng"):
                 raise ValueError(f"PGX_SEMANTICS: unknown switch {k!r}")
             kw[k] = v
         return cls(**kw)
 
     def oracle_kwargs(self) -> dict:
         """The same switches under the oracles' parameter names (tests only)."""
-        return {"soft_vertex_rule": self.soft_vertex, "coop_reward": self.coop_reward, "bad_action": self.bad_action,
+        return {"soft_vertex_rule": self.soft_vertex, "soft_occupancy": self.soft_occupancy, "coop_reward": self.coop_reward, "bad_action": self.bad_action,
                 "lifelong_rng": self.lifelong_rng}

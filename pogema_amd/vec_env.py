@@ -149,7 +149,8 @@ class VecPogema:
             outside_density=float(gc.density), soft_vertex_rule=_lib.SOFT_VERTEX_RULES[self.semantics.soft_vertex],
             coop_reward=_lib.COOP_REWARDS[self.semantics.coop_reward],
             bad_action=_lib.BAD_ACTIONS[self.semantics.bad_action],
-            lifelong_rng=_lib.LIFELONG_RNGS[self.semantics.lifelong_rng])
+            lifelong_rng=_lib.LIFELONG_RNGS[self.semantics.lifelong_rng],
+            soft_occupancy=_lib.SOFT_OCCUPANCY[self.semantics.soft_occupancy], reserved0=0)
         self._handle = C.c_void_p()
         _lib.check(self._lib.pgx_create(C.byref(cfg), self.device_index, C.byref(self._handle)))
         self._bufs = None

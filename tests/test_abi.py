@@ -30,8 +30,9 @@ def test_abi_version(engine_lib):
 
 
 def test_config_struct_layout():
-    # must match `struct pgx_config` in the header: 10 x int32, uint64, int64, int32, float, 4 x int32
-    assert C.sizeof(_lib.PgxConfig) == 10 * 4 + 8 + 8 + 4 + 4 + 4 * 4
+    # must match `struct pgx_config` in the header: 10 x int32, uint64, int64, int32, float, 6 x int32 (ABI 4)
+    assert C.sizeof(_lib.PgxConfig) == 10 * 4 + 8 + 8 + 4 + 4 + 6 * 4
+    assert _lib.PgxConfig.soft_occupancy.offset == 80 and _lib.PgxConfig.reserved0.offset == 84
     assert _lib.PgxConfig.soft_vertex_rule.offset == 64 and _lib.PgxConfig.bad_action.offset == 72
     assert _lib.PgxConfig.lifelong_rng.offset == 76
     assert _lib.PgxConfig.seed.offset == 40 and _lib.PgxConfig.env_index_base.offset == 48
@@ -43,7 +44,7 @@ def test_config_struct_layout():
     ("obs_radius", 0, "obs_radius"), ("obs_radius", 16, "obs_radius"), ("collision_system", 7, "collision"),
     ("on_target", -1, "on_target"), ("height", 0, "map size"), ("width", 4096, "map size"),
     ("soft_vertex_rule", 2, "semantics"), ("coop_reward", -1, "semantics"), ("bad_action", 3, "semantics"),
-    ("lifelong_rng", 2, "semantics"),
+    ("lifelong_rng", 2, "semantics"), ("soft_occupancy", 2, "semantics"), ("reserved0", 1, "semantics"),
 ])
 def test_create_rejects_bad_config(engine_lib, field, value, needle):
     cfg = _lib.PgxConfig(batch=4, height=8, width=8, num_agents=2, obs_radius=3, collision_system=0, on_target=0,

@@ -107,3 +107,30 @@ def test_closed_form_equals_literal_algorithm(collision, on_target, sc):
                 for j in range(i + 1, len(cur)):
                     if active[i] and active[j] and cur[i] != cur[j]:
                         assert not (g.positions_xy[i] == cur[j] and g.positions_xy[j] == cur[i])
+
+
+@pytest.mark.parametrize("rule", ["lowest_index", "all_stay"])
+@settings(max_examples=1500, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large])
+@given(sc=scenarios())
+def test_soft_occupancy_index_order_closed_form(rule, sc):
+    """docs/SPEC.md Q2 alternative (soft_occupancy='index_order'): the kernel's closed form of the literal per-agent
+    clear-old / set-new loop -- an agent is missing from the occupancy array iff it MOVED into a cell whose previous
+    occupant has a HIGHER index -- against the oracle's literal loop; positions themselves never depend on the switch."""
+    obstacles, starts, targets, actions = sc
+    kw = dict(obs_radius=1, collision_system="soft", on_target="nothing", max_episode_steps=1000, soft_vertex_rule=rule)
+    env = PogemaOracle(obstacles, starts, targets, soft_occupancy="index_order", **kw)
+    exact = PogemaOracle(obstacles, starts, targets, **kw)
+    g = env.grid
+    for acts in actions:
+        cur = list(g.positions_xy)
+        env.step(list(acts))
+        exact.step(list(acts))
+        new = list(g.positions_xy)
+        assert new == list(exact.grid.positions_xy)
+        standing = {c: j for j, c in enumerate(cur)}
+        expect = np.zeros_like(g.positions)
+        for i, c in enumerate(new):
+            ghost = c != cur[i] and standing.get(c, -1) > i
+            if not ghost:
+                expect[c] = 1
+        assert np.array_equal(expect, g.positions), (cur, acts, new)

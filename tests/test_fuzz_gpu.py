@@ -30,6 +30,7 @@ def _random_case(rng):
                 action_dtype=str(rng.choice(["int8", "int32", "int64"])), u8=bool(rng.integers(0, 2)),
                 seed=int(rng.integers(0, 2 ** 31)), base=int(rng.integers(0, 1000)),
                 soft_vertex=str(rng.choice(["lowest_index", "all_stay"])), coop_reward=str(rng.choice(["all_solved", "per_agent"])),
+                soft_occupancy=str(rng.choice(["exact", "index_order"])),
                 bad=bool(rng.integers(0, 4) == 0))
 
 
@@ -64,7 +65,8 @@ def test_random_configurations(chunk):
             actions = np.where(junk, rng.choice([-3, 5, 9, 100], size=actions.shape), actions)
         kw = dict(obs_radius=c["r"], collision_system=c["collision"], on_target=c["on_target"],
                   max_episode_steps=c["max_steps"], auto_reset=c["auto_reset"], seed=c["seed"] % 977,
-                  env_index_base=c["base"], semantics=Semantics(soft_vertex=c["soft_vertex"], coop_reward=c["coop_reward"]))
+                  env_index_base=c["base"], semantics=Semantics(soft_vertex=c["soft_vertex"], coop_reward=c["coop_reward"],
+                                                                     soft_occupancy=c["soft_occupancy"]))
         ref = c_oracle_rollout(o, a, t, actions, nthreads=4, **kw)
         got = engine_rollout(o, a, t, actions, action_dtype=c["action_dtype"],
                              obs_dtype=torch.uint8 if c["u8"] else None, **kw)

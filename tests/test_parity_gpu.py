@@ -224,6 +224,33 @@ def test_semantics_variants(geom, on_target):
         assert_rollouts_equal(ref, got, f"variants/{name}/{on_target}/auto_reset={auto_reset}")
 
 
+@pytest.mark.parametrize("geom", VARIANT_GEOMS, ids=[g[0] for g in VARIANT_GEOMS])
+@pytest.mark.parametrize("rule", ["lowest_index", "all_stay"])
+def test_soft_occupancy_index_order(geom, rule):
+    """docs/SPEC.md Q2 alternative, Semantics(soft_occupancy='index_order'): the literal per-agent clear-old / set-new
+    loop of `move_without_checks` in index order -- an agent that follows a HIGHER-index agent is missing from the `agents`
+    planes of that step.  Engine (closed form: moved && occupant-of-destination index > own) vs the oracle's literal loop,
+    all episode modes, both vertex rules, auto-reset on and off; and the switch must actually change observations."""
+    from pogema_amd import Semantics
+    name, B, H, Wd, A, r, density, T, max_steps = geom
+    seed = zlib.crc32(f"occupancy/{name}/{rule}".encode()) % (2 ** 31)
+    obstacles, agents, targets = generate_instances(B, H, Wd, A, density, seed)
+    actions = random_actions(T, B, A, seed + 1, p_noop=0.1)
+    sem = Semantics(soft_vertex=rule, soft_occupancy="index_order")
+    changed = False
+    for on_target in ON_TARGET:
+        for auto_reset in (False, True):
+            kw = dict(obs_radius=r, collision_system="soft", on_target=on_target, max_episode_steps=max_steps,
+                      auto_reset=auto_reset, seed=77, env_index_base=3)
+            ref = oracle_rollout(obstacles, agents, targets, actions, semantics=sem, **kw)
+            got = engine_rollout(obstacles, agents, targets, actions, semantics=sem, **kw)
+            assert_rollouts_equal(ref, got, f"soft_occupancy/{name}/{rule}/{on_target}/auto_reset={auto_reset}")
+            exact = oracle_rollout(obstacles, agents, targets, actions, semantics=Semantics(soft_vertex=rule), **kw)
+            assert np.array_equal(exact["agents_xy"], ref["agents_xy"]), "the switch never changes where agents stand"
+            changed = changed or not np.array_equal(exact["obs"], ref["obs"])
+    assert changed or A < 4, "some follower of a higher-index agent must have gone missing from an agents plane"
+
+
 @pytest.mark.parametrize("A", [8, 64, 200])
 def test_all_stay_chains_and_rotations(A):
     """'all_stay' at the closure's extremes: a shoulder-to-shoulder line (free and blocked head) and crowds where

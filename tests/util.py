@@ -250,3 +250,5 @@ def check_spec_case(case, run):
             assert out[key][:, 0].astype(int).tolist() == exp[key], f"{key}: {case['why']}"
     if "obs0_agent0" in exp:
         assert out["obs0"][0, 0].astype(int).tolist() == exp["obs0_agent0"]
+    if "agents_plane" in exp:  # [T][A][W][W]: channel 1 (`Grid.get_positions`) of every agent's observation after each step
+        assert out["obs"][:, 0, :, 1].astype(int).tolist() == exp["agents_plane"], f"agents plane: {case['why']}"

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PGX_ABI_VERSION 4
+#define PGX_ABI_VERSION 5
 
 /* error codes */
 #define PGX_OK 0
@@ -50,20 +50,24 @@ extern "C" {
 #define PGX_ON_TARGET_RESTART 1
 #define PGX_ON_TARGET_NOTHING 2
 
-/* Switches for the semantics the builder recalls with LOW confidence (docs/SPEC.md open questions Q1, Q4, Q7; the
- * reference source is not mounted, /root/reference/README.md:3,5).  Value 0 is always the recalled-literal default;
- * the other value is the plausible alternative, so that pinning against the real package is a config flip, not a
- * kernel edit.  Every variant is implemented in the step kernel and in both oracles and covered by the parity matrix. */
+/* Switches for the semantics the builder recalls with LOW confidence (docs/SPEC.md open questions Q1, Q2, Q4, Q7; the
+ * reference source is not mounted, /root/reference/README.md:3,5).  Value 0 is ALWAYS the recalled-literal behaviour of
+ * upstream -- quirks included: bit-exactness targets what upstream does, not what would be tidier -- and the default of
+ * every host binding; the other value is the plausible alternative, so that pinning against the real package is a config
+ * flip, not a kernel edit.  Every variant is implemented in the step kernel and in both oracles and covered by the
+ * parity matrix. */
 #define PGX_SOFT_LOWEST_INDEX_WINS 0 /* Q1: `soft`, several movers claim one free/vacated cell: the lowest index moves
                                         (literal `used_cells[cell].remove(agent)` + reverse-index loop)               */
 #define PGX_SOFT_ALL_STAY 1          /* Q1 alternative: every claimant of a contested cell stays (textbook MAPF)       */
 #define PGX_COOP_REWARD_ALL_SOLVED 0 /* Q4: on_target = NOTHING pays 1.0 to every agent iff ALL are on their goals    */
 #define PGX_COOP_REWARD_PER_AGENT 1  /* Q4 alternative: 1.0 to each agent standing on its own goal in this step        */
-#define PGX_SOFT_OCCUPANCY_EXACT 0       /* Q2: after a `soft` step the occupancy array (`Grid.positions`, the `agents` plane of
-                                           the observations) is exactly the set of visible agents' cells              */
-#define PGX_SOFT_OCCUPANCY_INDEX_ORDER 1 /* Q2 alternative: the literal `Grid.move_without_checks` loop as recalled -- clear the
-                                           old cell, set the new one, agent by agent in index order: an agent entering the
-                                           cell a HIGHER-index agent is leaving is missing from this step's `agents` planes */
+#define PGX_SOFT_OCCUPANCY_INDEX_ORDER 0 /* Q2: the literal `Grid.move_without_checks` loop as recalled -- clear the old cell,
+                                           set the new one, agent by agent in index order: an agent entering the cell a
+                                           HIGHER-index agent is leaving stands there but is missing from the occupancy
+                                           array (`Grid.positions`: the `agents` planes, pgx_get_state's occupancy) until
+                                           its next turn in a later step re-sets it.  (ABI <= 4 numbered this 1.)        */
+#define PGX_SOFT_OCCUPANCY_EXACT 1       /* Q2 alternative: after a `soft` step the occupancy array is exactly the set of
+                                           visible agents' cells (the invariant every other collision system keeps)      */
 #define PGX_BAD_ACTION_NOOP 0        /* Q7: an action outside 0..4 is a noop                                           */
 #define PGX_BAD_ACTION_FLAG 1        /* Q7 alternative: still a noop on the device, but counted -- pgx_bad_action_count()
                                         lets the host raise the reference's IndexError                               */
@@ -120,7 +124,7 @@ typedef struct pgx_config {
     int32_t coop_reward;       /* PGX_COOP_REWARD_* (0 = recalled)                                       */
     int32_t bad_action;        /* PGX_BAD_ACTION_*  (0 = noop)                                           */
     int32_t lifelong_rng;      /* PGX_LIFELONG_RNG_* (0 = the build's counter-based stream)              */
-    int32_t soft_occupancy;    /* PGX_SOFT_OCCUPANCY_* (0 = occupancy == cells of the visible agents)    */
+    int32_t soft_occupancy;    /* PGX_SOFT_OCCUPANCY_* (0 = the literal index-order loop, recalled)      */
     int32_t reserved0;         /* must be 0                                                              */
 } pgx_config;
 

@@ -16,7 +16,7 @@ ON_TARGET = {"finish": 0, "restart": 1, "nothing": 2}
 SOFT_VERTEX_RULE = {"lowest_index": 0, "all_stay": 1}
 COOP_REWARD = {"all_solved": 0, "per_agent": 1}
 BAD_ACTION = {"noop": 0, "flag": 1}
-SOFT_OCCUPANCY = {"exact": 0, "index_order": 1}
+SOFT_OCCUPANCY = {"index_order": 0, "exact": 1}
 
 
 class PoConfig(C.Structure):
@@ -60,7 +60,7 @@ class COracle:
     def __init__(self, batch, height, width, num_agents, obs_radius, collision_system="priority", on_target="finish",
                  max_episode_steps=64, auto_reset=False, seed=0, env_index_base=0, empty_outside=True,
                  outside_density=0.0, soft_vertex_rule="lowest_index", coop_reward="all_solved", bad_action="noop",
-                 lifelong_rng="build", soft_occupancy="exact"):
+                 lifelong_rng="build", soft_occupancy="index_order"):
         if lifelong_rng != "build":
             raise NotImplementedError("the plain-C port has the build's lifelong stream only; use the Python oracle")
         self.lib = load()

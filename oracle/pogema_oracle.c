@@ -31,11 +31,11 @@ typedef struct po_config {
     int64_t env_index_base;
     int32_t random_outside;   /* empty_outside=False: Bernoulli(outside_density) obstacles beyond the ring */
     float outside_density;
-    /* switches for the low-confidence recollections (docs/SPEC.md Q1 / Q4 / Q7); 0 = recalled default */
+    /* switches for the low-confidence recollections (docs/SPEC.md Q1 / Q2 / Q4 / Q7); 0 = recalled literal = default */
     int32_t soft_vertex_rule; /* 0 lowest index wins a contested cell (literal remove + reverse loop), 1 all claimants stay */
     int32_t coop_reward;      /* 0 1.0 to all iff all on goal, 1 1.0 to each agent on its own goal */
     int32_t bad_action;       /* 0 out-of-range action = noop, 1 noop + counted (po_bad_action_count) */
-    int32_t soft_occupancy;   /* docs/SPEC.md Q2: 0 occupancy == cells of the visible agents; 1 the literal per-agent
+    int32_t soft_occupancy;   /* docs/SPEC.md Q2: 1 occupancy == cells of the visible agents; 0 the literal per-agent
                                  move_without_checks loop (clear old, set new, in index order) as recalled */
 } po_config;
 
@@ -300,21 +300,21 @@ static void revert_action(po_env* e, int b, scratch* s, int agent, int cell) {
 }
 
 /* Grid.move_without_checks for every active agent once the surviving `soft` moves are known (docs/SPEC.md Q2).
- * soft_occupancy 0: the occupancy array afterwards is exactly the set of active agents' cells; 1: the literal loop as
+ * soft_occupancy 1: the occupancy array afterwards is exactly the set of active agents' cells; 0: the literal loop as
  * recalled -- clear the old cell, set the new one, agent by agent in index order (an agent entering the cell a HIGHER-index
  * agent is leaving has its new cell cleared again by that agent's turn). */
 static void apply_soft_moves(po_env* e, int b, const int8_t* acts) {
     const int A = e->c.num_agents, PW = e->PW;
     const size_t base = (size_t)b * A;
     uint8_t* occ = e->occ + (size_t)b * e->PH * e->PW;
-    if (e->c.soft_occupancy == 0) {
+    if (e->c.soft_occupancy != 0) {
         for (int i = 0; i < A; ++i)
             if (e->active[base + i]) occ[(size_t)e->px[base + i] * PW + e->py[base + i]] = 0;
     }
     for (int i = 0; i < A; ++i) {
         if (!e->active[base + i]) continue;
         const int a = acts[i];
-        if (e->c.soft_occupancy != 0) occ[(size_t)e->px[base + i] * PW + e->py[base + i]] = 0;
+        if (e->c.soft_occupancy == 0) occ[(size_t)e->px[base + i] * PW + e->py[base + i]] = 0;
         e->px[base + i] += MOVE_DX[a];
         e->py[base + i] += MOVE_DY[a];
         occ[(size_t)e->px[base + i] * PW + e->py[base + i]] = 1;

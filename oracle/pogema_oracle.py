@@ -196,7 +196,7 @@ class PogemaOracle:
 
     def __init__(self, obstacles, agents_xy, targets_xy, obs_radius=5, collision_system="priority",
                  on_target="finish", max_episode_steps=64, auto_reset=False, seed=0, env_index=0,
-                 empty_outside=True, outside_density=0.0, epoch=0, soft_vertex_rule="lowest_index", soft_occupancy="exact",
+                 empty_outside=True, outside_density=0.0, epoch=0, soft_vertex_rule="lowest_index", soft_occupancy="index_order",
                  coop_reward="all_solved", bad_action="noop", lifelong_rng="build"):
         assert collision_system in COLLISION_SYSTEMS and on_target in ON_TARGET
         assert soft_vertex_rule in SOFT_VERTEX_RULES and coop_reward in COOP_REWARDS and bad_action in BAD_ACTIONS
@@ -346,11 +346,11 @@ class PogemaOracle:
 
     def _apply_soft_moves(self, actions):
         """`move_without_checks` for every active agent (the surviving moves are mutually compatible).  docs/SPEC.md Q2:
-        'exact' (default): the occupancy array afterwards is exactly the set of active agents' cells; 'index_order': the
-        literal per-agent loop as recalled -- clear the old cell, set the new one, agent by agent in index order -- in which
-        an agent that enters the cell a HIGHER-index agent is leaving has its new cell cleared again by that agent's
-        turn: it stands there but is missing from the occupancy array (and from everybody's `agents` plane) until its
-        next turn re-sets it."""
+        'index_order' (default, the recalled literal): the per-agent loop -- clear the old cell, set the new one, agent by
+        agent in index order -- in which an agent that enters the cell a HIGHER-index agent is leaving has its new cell
+        cleared again by that agent's turn: it stands there but is missing from the occupancy array (and from everybody's
+        `agents` plane) until its next turn in a later step re-sets it; 'exact' (the alternative): the occupancy array
+        afterwards is exactly the set of active agents' cells."""
         g = self.grid
         n = self.num_agents
         if self.soft_occupancy == "index_order":

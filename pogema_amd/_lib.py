@@ -12,13 +12,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PGX_LIB: diagnostic override (A/B of two builds of the SAME engine on one box); never a fallback
 LIB_PATH = os.environ.get("PGX_LIB") or os.path.join(_HERE, "libpogema_amd.so")
 
-PGX_ABI_VERSION = 4
+PGX_ABI_VERSION = 5
 
 COLLISION_SYSTEMS = {"priority": 0, "block_both": 1, "soft": 2}
 ON_TARGET = {"finish": 0, "restart": 1, "nothing": 2}
 ACTION_DTYPES = {"int8": 0, "int32": 1, "int64": 2}
 SOFT_VERTEX_RULES = {"lowest_index": 0, "all_stay": 1}
-SOFT_OCCUPANCY = {"exact": 0, "index_order": 1}
+SOFT_OCCUPANCY = {"index_order": 0, "exact": 1}
 COOP_REWARDS = {"all_solved": 0, "per_agent": 1}
 BAD_ACTIONS = {"noop": 0, "flag": 1}
 LIFELONG_RNGS = {"build": 0, "numpy": 1}

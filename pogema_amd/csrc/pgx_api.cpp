@@ -182,7 +182,10 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
             const std::string v = f;
             g->store_policy = v == "plain" ? 0 : v == "nt" ? 1 : v == "sc1" ? 2 : g->store_policy;
         }
-        if (const char* f = getenv("PGX_STATE_STORES")) g->state_stores = atoi(f);  // tuning/diagnostic override: 0 | 1 | 2
+        if (const char* f = getenv("PGX_STATE_STORES")) {  // tuning/diagnostic override: 0 | 1 | 2; anything else is ignored
+            const int v = atoi(f);  // (an out-of-range value would make emit_state() fire at NO call site: state never written)
+            if (v >= 0 && v <= 2 && f[0] >= '0' && f[0] <= '2' && f[1] == 0) g->state_stores = v;
+        }
         if (const char* f = getenv("PGX_LDS_MIN")) {  // diagnostic: cap residency by reserving LDS per workgroup
             const size_t m = (size_t)atol(f);
             if (m > g->lds_bytes) g->lds_bytes = (m + 15) & ~(size_t)15;

@@ -9,6 +9,9 @@ namespace pgx {
 enum { MODE_STEP = 0, MODE_OBSERVE = 1 };
 enum { COLLISION_PRIORITY = 0, COLLISION_BLOCK_BOTH = 1, COLLISION_SOFT = 2 };
 enum { ON_TARGET_FINISH = 0, ON_TARGET_RESTART = 1, ON_TARGET_NOTHING = 2 };
+// the per-agent `active` byte: bit 0 = `Grid.is_active`; bit 1 = the agent stands on its cell but is MISSING from the
+// occupancy array (`Grid.positions`) -- the quirk of the literal `move_without_checks` loop (docs/SPEC.md Q2), see step_body
+enum : uint32_t { ACTIVE_BIT = 1u, ACTIVE_GHOST = 2u };
 
 // ---- instance generator "GEN v2" constants shared by the host generator and the device kernels ----
 constexpr uint64_t GEN_TAG_OBST = 0x4F42535400000000ull;   // 'OBST'
@@ -70,7 +73,7 @@ struct StepParams {
     int32_t store_policy;  // observation stores: 0 plain, 1 nontemporal, 2 sc1 write-through (StepGeometry::store_policy)
     int32_t state_stores;  // when the small per-step result stores are issued: 0 at once, 1 after the LDS barrier, 2 after the stream
     int32_t soft_rule;    // PGX_SOFT_*  (docs/SPEC.md Q1)
-    int32_t soft_occupancy;  // PGX_SOFT_OCCUPANCY_* (Q2)
+    int32_t soft_occupancy;  // PGX_SOFT_OCCUPANCY_* (Q2; 0 = the literal index-order loop)
     int32_t coop_reward;  // PGX_COOP_REWARD_* (Q4)
     int32_t bad_action;   // PGX_BAD_ACTION_* (Q7)
     int32_t xcd_n[8];     // workgroups (= environment slices) given to each XCD, proportional to its measured store rate
@@ -82,7 +85,7 @@ struct StepParams {
     const uint32_t* obst;  // [B][bm_words]   padded obstacle bitmap, 1 bit per cell
     uint32_t* pos;         // [B][A]          (x << 16) | y, padded coordinates
     uint32_t* tgt;         // [B][A]
-    uint8_t* active;       // [B][A]
+    uint8_t* active;       // [B][A]          ACTIVE_BIT | ACTIVE_GHOST
     int32_t* elapsed;      // [B]
     const uint32_t* pos0;  // [B][A]          auto-reset state
     const uint32_t* tgt0;  // [B][A]

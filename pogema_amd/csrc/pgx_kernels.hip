@@ -270,7 +270,8 @@ __device__ __forceinline__ void stream_rows16_loop(f32x4_t* out4, const uint32_t
         // software pipeline: the row words of iteration k+1 are read from LDS while iteration k is converted and stored
         // (the compiler does not do it: one exposed LDS round trip per 1-KiB store otherwise; configs[2] 113.8 -> 112.9 us,
         // profiles/r3/stream_loop_ab.txt); the read past the last iteration is clamped to the zero pad behind the rows
-        uint32_t w0 = rows32[row >> 1], w1 = rows32[(row >> 1) + 1];
+        const int fw = min(row >> 1, last_word);  // (a lane with q0 >= q1 starts beyond the rows: clamped like the in-loop read)
+        uint32_t w0 = rows32[fw], w1 = rows32[fw + 1];
         for (int q = q0; q < q1; q += qs) {
             int ncol = col + dcol, nrow = row + drow;
             if (ncol >= W) {
@@ -427,11 +428,14 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
 
     uint32_t pos = 0u, tgt = 1u;
     bool active = false;
+    bool ghost_in = false;  // ACTIVE_GHOST of the stored byte (see `ghost` below)
     int act = 0, elapsed = 0;
     if (valid) {
         pos = p.pos[gi];
         tgt = p.tgt[gi];
-        active = p.active[gi] != 0;
+        const uint32_t ab = p.active[gi];
+        active = (ab & ACTIVE_BIT) != 0;
+        ghost_in = (ab & ACTIVE_GHOST) != 0;
         if (p.mode == MODE_STEP) {
             const size_t ai = ROLL ? gi + (size_t)t * (size_t)rp.agents_stride : gi;
             if (ROLL && p.actions == nullptr) {  // the engine's own uniform random policy
@@ -492,6 +496,15 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
     // 25 us), so WHEN they are issued matters (StepParams::state_stores): 0 right after they are known, 1 after the
     // cells have been published to LDS and the barrier has been passed (helper waves no longer wait for them),
     // 2 after the wave's own observation stream (nobody waits for them at all).
+    // docs/SPEC.md Q2, PGX_SOFT_OCCUPANCY_INDEX_ORDER (the recalled literal, value 0): upstream's per-agent clear-old /
+    // set-new loop in index order leaves an agent that entered the cell a HIGHER-index agent is leaving out of the
+    // occupancy array (that agent's turn clears the cell again) -- closed form of the literal loop: moved &&
+    // occupant-of-destination index > own.  `Grid.positions` is persistent state upstream: the agent stays missing until a
+    // later step's loop re-sets it, so the flag is kept with the agent (bit ACTIVE_GHOST of the `active` byte, written by
+    // emit_state) and honoured by every launch that only LOOKS at the state (MODE_OBSERVE: pgx_observe, the masked observe
+    // after pgx_regenerate; pgx_get_state's occupancy; snapshots carry the byte).  A step recomputes it from scratch: every
+    // active agent takes its turn in the loop again.
+    bool ghost = p.mode != MODE_STEP && ghost_in;
     struct StateOut {
         float rew = 0.0f;
         uint8_t term = 0;
@@ -511,7 +524,7 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
             if (o.do_reset && p.np_state) p.np_state[gi] = p.np_state0[gi];  // upstream re-creates the generators in reset()
             p.pos[gi] = pos_;
             p.tgt[gi] = tgt_;
-            p.active[gi] = active_ ? 1 : 0;
+            p.active[gi] = active_ ? (uint8_t)(ACTIVE_BIT | (ghost ? ACTIVE_GHOST : 0u)) : (uint8_t)0;
         }
         if (env_leader) {
             p.elapsed[env] = o.do_reset ? 0 : elapsed_;
@@ -555,10 +568,6 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
         }
         uint32_t cur = to_c22(pos);                     // 22-bit key of the own cell
         uint32_t vis = active ? cur : NOCELL_A;         // ... as seen by others (hidden agents stand nowhere)
-        // docs/SPEC.md Q2, PGX_SOFT_OCCUPANCY_INDEX_ORDER: upstream's per-agent clear-old / set-new loop in index order
-        // leaves an agent that entered the cell a HIGHER-index agent is leaving out of the occupancy array (that agent's
-        // turn clears the cell again) -- closed form of the literal loop: moved && occupant-of-destination index > own
-        bool ghost = false;
 
         if (p.mode == MODE_STEP) {
             // ================= move + collision resolve =========================================
@@ -656,7 +665,7 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
                 cur = want;
                 vis = want;
                 pos = from_c22(want);
-                ghost = p.soft_occupancy != 0 && p.collision == COLLISION_SOFT && okey < 1024u && (int)okey > i;
+                ghost = p.soft_occupancy == 0 && p.collision == COLLISION_SOFT && okey < 1024u && (int)okey > i;
             }
 
             // ================= goals, rewards, done flags ==========
@@ -691,6 +700,7 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
             if (fin && on_goal) {  // hide_agent
                 active = false;
                 vis = NOCELL_A;
+                ghost = false;
             }
             if (p.on_target == ON_TARGET_RESTART && on_goal) {
                 const uint32_t x = (pos >> 16) - r, y = (pos & 0xFFFFu) - r;
@@ -1122,7 +1132,7 @@ __global__ void unpack_state_kernel(const uint32_t* __restrict__ pos, const uint
         target_xy[2 * i] = (int32_t)(tgt[i] >> 16) - r;
         target_xy[2 * i + 1] = (int32_t)(tgt[i] & 0xFFFFu) - r;
     }
-    if (act_out) act_out[i] = active[i];
+    if (act_out) act_out[i] = active[i] & ACTIVE_BIT;
 }
 
 // occupancy export: u8 [B, PH, PW]; must be zero-filled by the caller (hipMemsetAsync) first.
@@ -1130,7 +1140,7 @@ __global__ void occupancy_kernel(const uint32_t* __restrict__ pos, const uint8_t
                                  uint8_t* __restrict__ occ, size_t n, int A, int PH, int PW) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (!active[i]) return;
+    if ((active[i] & (ACTIVE_BIT | ACTIVE_GHOST)) != ACTIVE_BIT) return;  // hidden, or standing there unseen (Q2 literal)
     const size_t env = i / A;
     const uint32_t x = pos[i] >> 16, y = pos[i] & 0xFFFFu;
     occ[(env * PH + x) * PW + y] = 1;

@@ -1,8 +1,11 @@
 """Switches for the semantics of the reference that the builder recalls with LOW confidence.
 
+Every DEFAULT is the recalled literal behaviour of upstream, quirks included (bit-exactness targets what upstream does,
+not what would be tidier); the other value is the plausible alternative.
+
 The reference source is not mounted (/root/reference/README.md:3,5 -- "code is hosted elsewhere"), so a few details
 of upstream `pogema/envs.py` are recollections that the real package may contradict (docs/SPEC.md open questions
-Q1, Q4, Q7).  Each is a configuration switch -- implemented in the step kernel, in both oracles and in the parity
+Q1, Q2, Q4, Q7).  Each is a configuration switch -- implemented in the step kernel, in both oracles and in the parity
 matrix -- so that pinning against the real package is a flip here, not a kernel edit:
 
     soft_vertex   'lowest_index' (default): collision_system='soft', several movers claim one free or vacated cell:
@@ -10,12 +13,15 @@ matrix -- so that pinning against the real package is a flip here, not a kernel 
                                  + reverse-index loop + recursive `_revert_action`, as recalled);
                   'all_stay'   : every claimant of a contested cell stays (the textbook MAPF vertex-conflict rule,
                                  SURVEY.md A5's one-line "net semantics").
-    soft_occupancy 'exact' (default): after a `soft` step the occupancy array (`Grid.positions`, the `agents` plane of every
-                                 observation) is exactly the set of visible agents' cells;
-                  'index_order': the literal `move_without_checks` loop as recalled (Q2) -- clear the old cell, set the new
-                                 one, agent by agent in index order: an agent that enters the cell a HIGHER-index agent
-                                 is leaving gets its new cell cleared again by that agent's turn and is missing from
-                                 the `agents` planes of this step's observations (its next turn re-sets it).
+    soft_occupancy 'index_order' (default): the literal `move_without_checks` loop as recalled (Q2) -- clear the old cell,
+                                 set the new one, agent by agent in index order: an agent that enters the cell a
+                                 HIGHER-index agent is leaving gets its new cell cleared again by that agent's turn; it
+                                 stands there but is missing from the occupancy array (`Grid.positions`: the `agents`
+                                 plane of every observation, `get_state(occupancy=True)`) until its turn in a LATER step
+                                 re-sets it -- persistent, as upstream's array is: `observe()`, snapshots and
+                                 `step(compute_obs=False)` + `observe()` all show the same array as the step itself;
+                  'exact'      : after a `soft` step the occupancy array is exactly the set of visible agents' cells
+                                 (the invariant every other collision system keeps).
     coop_reward   'all_solved' (default): on_target='nothing' pays 1.0 to every agent iff ALL agents stand on their
                                  goals (`is_task_solved`);
                   'per_agent'  : 1.0 to each agent standing on its own goal in this step.
@@ -49,7 +55,7 @@ from dataclasses import dataclass
 
 LIFELONG_RNG = ("build", "numpy")
 SOFT_VERTEX = ("lowest_index", "all_stay")
-SOFT_OCCUPANCY = ("exact", "index_order")
+SOFT_OCCUPANCY = ("index_order", "exact")
 COOP_REWARD = ("all_solved", "per_agent")
 BAD_ACTION = ("noop", "flag")
 GENERATOR_RNG = ("build", "numpy")
@@ -58,7 +64,7 @@ GENERATOR_RNG = ("build", "numpy")
 @dataclass(frozen=True)
 class Semantics:
     soft_vertex: str = "lowest_index"
-    soft_occupancy: str = "exact"
+    soft_occupancy: str = "index_order"
     coop_reward: str = "all_solved"
     bad_action: str = "noop"
     lifelong_rng: str = "build"

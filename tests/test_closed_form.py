@@ -85,7 +85,7 @@ def test_closed_form_equals_literal_algorithm(collision, on_target, sc):
     collision, _, rule = collision.partition("/")  # 'soft/all_stay': the docs/SPEC.md Q1 alternative
     rule = rule or "lowest_index"
     env = PogemaOracle(obstacles, starts, targets, obs_radius=1, collision_system=collision, on_target=on_target,
-                       max_episode_steps=1000, soft_vertex_rule=rule)
+                       max_episode_steps=1000, soft_vertex_rule=rule, soft_occupancy="exact")
     g = env.grid
     for acts in actions:
         cur = list(g.positions_xy)
@@ -101,6 +101,7 @@ def test_closed_form_equals_literal_algorithm(collision, on_target, sc):
         occ = np.zeros_like(g.positions)
         for p in vis:
             occ[p] = 1
+        # (under `soft` this is the Q2 ALTERNATIVE, soft_occupancy='exact'; the default literal loop: next test)
         assert np.array_equal(occ, g.positions), "occupancy array == cells of the visible agents"
         if collision != "priority":  # no edge swaps under block_both / soft
             for i in range(len(cur)):
@@ -113,13 +114,16 @@ def test_closed_form_equals_literal_algorithm(collision, on_target, sc):
 @settings(max_examples=1500, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large])
 @given(sc=scenarios())
 def test_soft_occupancy_index_order_closed_form(rule, sc):
-    """docs/SPEC.md Q2 alternative (soft_occupancy='index_order'): the kernel's closed form of the literal per-agent
-    clear-old / set-new loop -- an agent is missing from the occupancy array iff it MOVED into a cell whose previous
-    occupant has a HIGHER index -- against the oracle's literal loop; positions themselves never depend on the switch."""
+    """docs/SPEC.md Q2 default (soft_occupancy='index_order', the recalled literal): the kernel's closed form of the
+    per-agent clear-old / set-new loop -- an agent is missing from the occupancy array iff it MOVED into a cell whose
+    previous occupant has a HIGHER index, and a step recomputes that from scratch (every active agent takes its turn
+    again, so last step's missing agents reappear unless they qualify anew) -- against the oracle's literal loop over
+    its PERSISTENT array; positions themselves never depend on the switch."""
     obstacles, starts, targets, actions = sc
     kw = dict(obs_radius=1, collision_system="soft", on_target="nothing", max_episode_steps=1000, soft_vertex_rule=rule)
-    env = PogemaOracle(obstacles, starts, targets, soft_occupancy="index_order", **kw)
-    exact = PogemaOracle(obstacles, starts, targets, **kw)
+    env = PogemaOracle(obstacles, starts, targets, **kw)
+    assert env.soft_occupancy == "index_order", "the default is the recalled literal"
+    exact = PogemaOracle(obstacles, starts, targets, soft_occupancy="exact", **kw)
     g = env.grid
     for acts in actions:
         cur = list(g.positions_xy)

@@ -227,16 +227,19 @@ def test_semantics_variants(geom, on_target):
 @pytest.mark.parametrize("geom", VARIANT_GEOMS, ids=[g[0] for g in VARIANT_GEOMS])
 @pytest.mark.parametrize("rule", ["lowest_index", "all_stay"])
 def test_soft_occupancy_index_order(geom, rule):
-    """docs/SPEC.md Q2 alternative, Semantics(soft_occupancy='index_order'): the literal per-agent clear-old / set-new
-    loop of `move_without_checks` in index order -- an agent that follows a HIGHER-index agent is missing from the `agents`
-    planes of that step.  Engine (closed form: moved && occupant-of-destination index > own) vs the oracle's literal loop,
-    all episode modes, both vertex rules, auto-reset on and off; and the switch must actually change observations."""
+    """docs/SPEC.md Q2, both positions of Semantics.soft_occupancy.  'index_order' (the default, recalled literal): the
+    per-agent clear-old / set-new loop of `move_without_checks` in index order -- an agent that follows a HIGHER-index agent
+    is missing from the `agents` planes until a later step re-sets it.  Engine (closed form: moved && occupant-of-destination
+    index > own) vs the oracle's literal loop, all episode modes, both vertex rules, auto-reset on and off; the alternative
+    'exact' likewise; and the switch must actually change observations."""
     from pogema_amd import Semantics
     name, B, H, Wd, A, r, density, T, max_steps = geom
     seed = zlib.crc32(f"occupancy/{name}/{rule}".encode()) % (2 ** 31)
     obstacles, agents, targets = generate_instances(B, H, Wd, A, density, seed)
     actions = random_actions(T, B, A, seed + 1, p_noop=0.1)
-    sem = Semantics(soft_vertex=rule, soft_occupancy="index_order")
+    sem = Semantics(soft_vertex=rule)
+    assert sem.soft_occupancy == "index_order", "every default is the recalled literal (docs/SPEC.md)"
+    alt = Semantics(soft_vertex=rule, soft_occupancy="exact")
     changed = False
     for on_target in ON_TARGET:
         for auto_reset in (False, True):
@@ -245,10 +248,65 @@ def test_soft_occupancy_index_order(geom, rule):
             ref = oracle_rollout(obstacles, agents, targets, actions, semantics=sem, **kw)
             got = engine_rollout(obstacles, agents, targets, actions, semantics=sem, **kw)
             assert_rollouts_equal(ref, got, f"soft_occupancy/{name}/{rule}/{on_target}/auto_reset={auto_reset}")
-            exact = oracle_rollout(obstacles, agents, targets, actions, semantics=Semantics(soft_vertex=rule), **kw)
+            exact = oracle_rollout(obstacles, agents, targets, actions, semantics=alt, **kw)
+            got = engine_rollout(obstacles, agents, targets, actions, semantics=alt, **kw)
+            assert_rollouts_equal(exact, got, f"soft_occupancy=exact/{name}/{rule}/{on_target}/auto_reset={auto_reset}")
             assert np.array_equal(exact["agents_xy"], ref["agents_xy"]), "the switch never changes where agents stand"
             changed = changed or not np.array_equal(exact["obs"], ref["obs"])
     assert changed or A < 4, "some follower of a higher-index agent must have gone missing from an agents plane"
+
+
+@pytest.mark.parametrize("on_target", ["finish", "nothing", "restart"])
+@pytest.mark.parametrize("geom", [("one_wave", 6, 12, 12, 14, 3), ("helper_waves", 3, 20, 20, 64, 5), ("two_slots", 2, 18, 18, 100, 3)],
+                         ids=lambda g: g[0])
+def test_soft_occupancy_is_persistent_state(geom, on_target):
+    """`Grid.positions` is STATE upstream: an agent the literal `move_without_checks` loop left out of the array stays out
+    until a later step's loop re-sets it.  So under the default semantics everything that only LOOKS at the
+    state must show what the step itself showed: step(compute_obs=False) + observe(), get_state(occupancy=True), a
+    save_state()/load_state() round trip -- against the C oracle's persistent array, at every step."""
+    import torch
+    from oracle.c_oracle import COracle
+    from pogema_amd import GridConfig, VecPogema
+    name, B, H, Wd, A, r = geom
+    seed = zlib.crc32(f"persistent/{name}/{on_target}".encode()) % (2 ** 31)
+    obstacles, agents, targets = generate_instances(B, H, Wd, A, 0.1, seed)
+    actions = random_actions(14, B, A, seed + 1, p_noop=0.05)
+    gc = GridConfig(map=obstacles[0].tolist(), num_agents=A, obs_radius=r, collision_system="soft", on_target=on_target,
+                    max_episode_steps=9, seed=5)
+    env = VecPogema(gc, batch=B, auto_reset=True, env_index_base=2)
+    obs = env.reset_from_state(obstacles, agents, targets)
+    ref = COracle(B, H, Wd, A, r, "soft", on_target, 9, True, seed=5, env_index_base=2)
+    assert np.array_equal(obs.cpu().numpy(), ref.reset(obstacles, agents, targets))
+    d_actions = torch.from_numpy(actions).to("cuda:0")
+    missing, kept = 0, None
+    for t in range(actions.shape[0]):
+        out = env.step(d_actions[t], compute_obs=False)
+        assert out[0] is None
+        robs, *_ = ref.step(actions[t])
+        looked = env.observe().cpu().numpy()
+        assert np.array_equal(looked, robs), f"step {t}: observe() after the step differs from the step's own observation"
+        st, rst = env.get_state(occupancy=True), ref.get_state(occupancy=True)
+        occ = st["occupancy"].cpu().numpy()
+        assert np.array_equal(occ, rst["occupancy"]), f"step {t}: occupancy array"
+        assert np.array_equal(st["is_active"].cpu().numpy(), rst["is_active"]), "is_active carries no ghost bit"
+        missing += int(rst["is_active"].sum() - occ.sum())
+        if t == 6:
+            kept = (env.save_state(), looked, occ)
+    assert missing > 0, "no follower of a higher-index agent went missing: the scenario does not exercise the quirk"
+    env.load_state(kept[0])
+    assert np.array_equal(env.observe().cpu().numpy(), kept[1]), "snapshot round trip loses the occupancy array"
+    assert np.array_equal(env.get_state(occupancy=True)["occupancy"].cpu().numpy(), kept[2])
+    # the same call sequence with observations computed by the step: identical
+    env2 = VecPogema(gc, batch=B, auto_reset=True, env_index_base=2)
+    env2.reset_from_state(obstacles, agents, targets)
+    env.reset_from_state(obstacles, agents, targets)
+    for t in range(6):
+        a = env2.step(d_actions[t])[0].cpu().numpy()
+        env.step(d_actions[t], compute_obs=False)
+        assert np.array_equal(a, env.observe().cpu().numpy())
+    env.close()
+    env2.close()
+    ref.close()
 
 
 @pytest.mark.parametrize("A", [8, 64, 200])

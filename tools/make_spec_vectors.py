@@ -137,23 +137,28 @@ case("bad_action_inactive", "Q7 alternative: a finished (hidden) agent's action 
 
 # --- Q2: the occupancy array after a `soft` step ------------------------------------------------------------------
 both_visible = [[[0, 0, 0], [0, 1, 1], [0, 0, 0]], [[0, 0, 0], [1, 1, 0], [0, 0, 0]]]  # agents planes of agent 0 / agent 1
-case("follow_occupancy", "Q2 default: agent 0 (0,0)->(0,1) follows agent 1 (0,1)->(0,2); afterwards the occupancy array is "
-     "exactly the two agents' cells, so each sees itself in the centre and the other next to it; a noop step changes nothing",
-     OPEN3, [[0, 0], [0, 1]], far, [[RIGHT, RIGHT], [NOOP, NOOP]], "soft",
-     dict(agents_xy=[[[0, 1], [0, 2]], [[0, 1], [0, 2]]], agents_plane=[both_visible, both_visible]))
-case("follow_occupancy", "Q2 alternative, literal move_without_checks in index order: agent 0 clears (0,0) and sets (0,1); then "
+case("follow_occupancy", "Q2 alternative (soft_occupancy='exact'): agent 0 (0,0)->(0,1) follows agent 1 (0,1)->(0,2); afterwards "
+     "the occupancy array is exactly the two agents' cells, so each sees itself in the centre and the other next to it; a noop "
+     "step changes nothing", OPEN3, [[0, 0], [0, 1]], far, [[RIGHT, RIGHT], [NOOP, NOOP]], "soft",
+     dict(agents_xy=[[[0, 1], [0, 2]], [[0, 1], [0, 2]]], agents_plane=[both_visible, both_visible]),
+     semantics={"soft_occupancy": "exact"})
+case("follow_occupancy", "Q2 default, literal move_without_checks in index order: agent 0 clears (0,0) and sets (0,1); then "
      "agent 1 clears ITS old cell (0,1) -- where agent 0 now stands -- and sets (0,2): agent 0 is missing from the occupancy "
      "array (its own centre cell and agent 1's left neighbour read 0); in the next step agent 0's own turn (a noop: clear, "
      "set) puts it back", OPEN3, [[0, 0], [0, 1]], far, [[RIGHT, RIGHT], [NOOP, NOOP]], "soft",
      dict(agents_xy=[[[0, 1], [0, 2]], [[0, 1], [0, 2]]],
-          agents_plane=[[[[0, 0, 0], [0, 0, 1], [0, 0, 0]], [[0, 0, 0], [0, 1, 0], [0, 0, 0]]], both_visible]),
-     semantics={"soft_occupancy": "index_order"})
-case("follow_occupancy", "Q2 alternative, lower index leads: agent 0 (0,1)->(0,2) sets (0,2) first, agent 1 (0,0)->(0,1) "
-     "then clears (0,0) and sets (0,1) -- nobody is cleared afterwards: identical with the default",
+          agents_plane=[[[[0, 0, 0], [0, 0, 1], [0, 0, 0]], [[0, 0, 0], [0, 1, 0], [0, 0, 0]]], both_visible]))
+case("follow_occupancy", "Q2 default, lower index leads: agent 0 (0,1)->(0,2) sets (0,2) first, agent 1 (0,0)->(0,1) "
+     "then clears (0,0) and sets (0,1) -- nobody is cleared afterwards: identical with the alternative",
      OPEN3, [[0, 1], [0, 0]], far, [[RIGHT, RIGHT]], "soft",
      dict(agents_xy=[[[0, 2], [0, 1]]],
-          agents_plane=[[[[0, 0, 0], [1, 1, 0], [0, 0, 0]], [[0, 0, 0], [0, 1, 1], [0, 0, 0]]]]),
-     semantics={"soft_occupancy": "index_order"})
+          agents_plane=[[[[0, 0, 0], [1, 1, 0], [0, 0, 0]], [[0, 0, 0], [0, 1, 1], [0, 0, 0]]]]))
+case("follow_occupancy", "Q2 default, three in a row moving right with the LAST index in front (agents 0,1 follow 2): agent 0 "
+     "(0,0)->(0,1) sets (0,1), agent 1 (0,1)->(0,2) clears (0,1) and sets (0,2), agent 2 (0,2)->(0,3) clears (0,2) and sets "
+     "(0,3): only agent 2 is left in the occupancy array; agent 0 sees nothing in its 3x3 window, agent 1 sees agent 2 to its "
+     "right, agent 2 sees itself", [[0, 0, 0, 0, 0]], [[0, 0], [0, 1], [0, 2]], [[0, 4], [0, 4], [0, 4]], [[RIGHT, RIGHT, RIGHT]], "soft",
+     dict(agents_xy=[[[0, 1], [0, 2], [0, 3]]],
+          agents_plane=[[[[0, 0, 0], [0, 0, 0], [0, 0, 0]], [[0, 0, 0], [0, 0, 1], [0, 0, 0]], [[0, 0, 0], [0, 1, 0], [0, 0, 0]]]]))
 
 out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "spec_vectors.json")
 with open(out, "w") as f:

@@ -16,6 +16,13 @@ Launch contract:
     line whose n_gpus differs from --gpus;
   * the batch shards over the ranks with no data-path collective; torch.distributed (RCCL) carries the barriers, the
     max-over-ranks clock and the per-rank kernel times only.
+Rehearsal: the builder's boxes have ONE GPU, so the N > 1 flow cannot be measured there -- but it
+can be EXECUTED: with PGX_BENCH_SHARE_DEVICE=1 rank r runs on device r % device_count (all ranks on cuda:0 of a 1-GPU
+box), torch.distributed uses gloo (RCCL refuses two ranks on one device) with host tensors for the clock / kernel-time
+exchange, every rank's zone walk is bounded to its share of the free memory, and the line is labelled REHEARSAL -- real
+engines, real launches, concurrent walks, the whole launcher / barrier / gather flow; not a measurement.
+PGX_BENCH_FORCE_DIST=1 initialises the process group even for one rank, so that the RCCL path (init with device_id,
+barrier, all_reduce, all_gather on device tensors) runs for real on a 1-GPU box (tests/test_bench_rehearsal_gpu.py).
 Timing: W warm-up steps, then `--windows` windows of EXACTLY K steps each, every window bracketed by barrier +
 torch.cuda.synchronize() on both sides and reduced with MAX over ranks; `value` comes from the MEDIAN window (a single
 20-step window is 2.6 ms of GPU time -- one lucky or unlucky sample), all windows are listed in the line.
@@ -125,6 +132,63 @@ def cpu_baseline(size, agents, r, collision, density, max_steps, target_seconds=
 
 
 # ----------------------------------------------------------------------------------------------------------
+# box fingerprint: what kind of MI355X is this?  (boxes of one pool differ by 25 % in store bandwidth and
+# some show no HBM "zones" at all -- the fingerprint lets such boxes be told apart by something other than timing)
+# ----------------------------------------------------------------------------------------------------------
+def _read(path, limit=4096):
+    try:
+        with open(path) as f:
+            return f.read(limit).strip()
+    except OSError:
+        return None
+
+
+def _props(path):
+    text = _read(path, 1 << 16)
+    if not text:
+        return {}
+    out = {}
+    for ln in text.splitlines():
+        k, _, v = ln.partition(" ")
+        out[k] = int(v) if v.strip().lstrip("-").isdigit() else v.strip()
+    return out
+
+
+def box_fingerprint():
+    """sysfs only (plain file reads: no child process, safe before and after the GPU is initialised): per GPU the
+    compute / memory partition modes (SPX/CPX..., NPS1/NPS4...), VRAM vendor and size, VBIOS, KFD node properties (XCCs,
+    SIMDs, clocks) and every memory bank (heap type, size, width, clock).  tools/box_probe.sh adds rocm-smi / amd-smi."""
+    import glob
+    cards = []
+    for dev in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+        if _read(os.path.join(dev, "vendor")) != "0x1002":
+            continue
+        cards.append({"card": os.path.basename(os.path.dirname(dev)), "device_id": _read(os.path.join(dev, "device")),
+                      "unique_id": _read(os.path.join(dev, "unique_id")),
+                      "compute_partition": _read(os.path.join(dev, "current_compute_partition")),
+                      "memory_partition": _read(os.path.join(dev, "current_memory_partition")),
+                      "vram_vendor": _read(os.path.join(dev, "mem_info_vram_vendor")),
+                      "vram_total": _read(os.path.join(dev, "mem_info_vram_total")),
+                      "vis_vram_total": _read(os.path.join(dev, "mem_info_vis_vram_total")),
+                      "vbios_version": _read(os.path.join(dev, "vbios_version")),
+                      "pcie_link": f"{_read(os.path.join(dev, 'current_link_speed'))} x{_read(os.path.join(dev, 'current_link_width'))}"})
+    nodes = []
+    for node in sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/[0-9]*"), key=lambda p: int(os.path.basename(p))):
+        pr = _props(os.path.join(node, "properties"))
+        if not pr.get("simd_count"):
+            continue  # CPU node
+        keep = ("gfx_target_version", "simd_count", "array_count", "num_xcc", "cu_per_simd_array", "simd_per_cu",
+                "max_engine_clk_fcompute", "local_mem_size", "device_id", "unique_id", "num_sdma_engines", "location_id")
+        banks = []
+        for bank in sorted(glob.glob(os.path.join(node, "mem_banks", "[0-9]*"))):
+            bp = _props(os.path.join(bank, "properties"))
+            banks.append({k: bp.get(k) for k in ("heap_type", "size_in_bytes", "flags", "width", "mem_clk_max")})
+        nodes.append({"node": int(os.path.basename(node)), **{k: pr.get(k) for k in keep}, "mem_banks": banks})
+    return {"drm_cards": cards, "kfd_gpu_nodes": nodes, "kernel": _read("/proc/sys/kernel/osrelease"),
+            "amdgpu_version": _read("/sys/module/amdgpu/version"), "hostname": socket.gethostname()}
+
+
+# ----------------------------------------------------------------------------------------------------------
 # launcher: `python bench.py --gpus N` without torchrun
 # ----------------------------------------------------------------------------------------------------------
 def _free_port() -> int:
@@ -140,12 +204,17 @@ def visible_device_count() -> int:
     return int(torch.cuda.device_count())
 
 
+def share_device() -> bool:
+    """PGX_BENCH_SHARE_DEVICE=1: rehearsal of the N > 1 flow on fewer devices than ranks (module docstring)."""
+    return os.environ.get("PGX_BENCH_SHARE_DEVICE", "0") not in ("", "0")
+
+
 def launch_ranks(n: int, argv, stub: bool = False) -> int:
     """Start `n` rank processes of this script (RANK = LOCAL_RANK = 0..n-1, rendezvous on 127.0.0.1) and wait for
     them.  Returns the worst exit code.  Rank 0's stdout (the JSON line) is passed through."""
     if not stub:
         have = visible_device_count()
-        if have < n:
+        if have < 1 or (have < n and not share_device()):
             print(f"bench.py: --gpus {n} requested but this box exposes {have} HIP device(s); refusing to print a "
                   f"line for fewer GPUs than asked", file=sys.stderr)
             return 2
@@ -174,24 +243,49 @@ def launch_ranks(n: int, argv, stub: bool = False) -> int:
 # ----------------------------------------------------------------------------------------------------------
 # the step under test
 # ----------------------------------------------------------------------------------------------------------
+def workload_grid_config(args, size, agents, r):
+    """The GridConfig every engine of this benchmark is built from."""
+    from pogema_amd import GridConfig
+    return GridConfig(size=size, density=args.density, num_agents=agents, obs_radius=r, seed=0,
+                      collision_system=args.collision, on_target=args.on_target, max_episode_steps=args.max_episode_steps)
+
+
+def placement_budget(args, world: int = 1):
+    """`placement_budget_gib` of every engine of this benchmark.  Default: None = the PRODUCT default (VecPogema walks
+    into another HBM zone only when the device is evidently its own, holding half of the free memory meanwhile) -- the
+    headline is what a default-constructed engine does.  `--placement-budget all|half|<GiB>` asks explicitly.
+    Rehearsal (ranks share a device): an explicit equal share of half of what is free now, so that `world`
+    concurrent walks cannot exhaust the device."""
+    if share_device() and world > 1:
+        import torch
+        free, _ = torch.cuda.mem_get_info()
+        return max(8.0, 0.5 * free / float(1 << 30) / world)
+    b = getattr(args, "placement_budget", "default")
+    return None if b == "default" else b if b in ("all", "half") else float(b)
+
+
+def build_env(args, device, batch, env_base, size, agents, r, placement_probe=True, buffers=None, world=1):
+    """The engine whose step() is timed as `value` (also what tests/test_fullsize_gpu.py compares its parity engines'
+    launch geometry with)."""
+    import torch
+    from pogema_amd import VecPogema
+    return VecPogema(workload_grid_config(args, size, agents, r), batch=batch, device=device, env_index_base=env_base,
+                     auto_reset=True if args.auto_reset == "restore" else "regenerate",
+                     # (--graph: the captured steps need fixed buffers -> two alternating sets)
+                     reuse_buffers={0: True if args.graph > 0 else "recycle", 1: "single", 2: True}[args.buffers]
+                     if buffers is None else buffers,
+                     obs_dtype=torch.float32 if args.obs_dtype == "float32" else torch.uint8,
+                     placement_probe=placement_probe,
+                     placement_budget_gib=placement_budget(args, world))
+
+
 class EngineStep:
     """The product path: VecPogema on this rank's device."""
 
-    def __init__(self, args, rank, device, batch, env_base, size, agents, r, placement_probe=True, buffers=None):
+    def __init__(self, args, rank, device, batch, env_base, size, agents, r, placement_probe=True, buffers=None, world=1):
         import torch
-        from pogema_amd import GridConfig, VecPogema
         self.torch = torch
-        gc = GridConfig(size=size, density=args.density, num_agents=agents, obs_radius=r, seed=0,
-                        collision_system=args.collision, on_target=args.on_target,
-                        max_episode_steps=args.max_episode_steps)
-        self.env = VecPogema(gc, batch=batch, device=device, env_index_base=env_base,
-                             auto_reset=True if args.auto_reset == "restore" else "regenerate",
-                             # (--graph: the captured steps need fixed buffers -> two alternating sets)
-                             reuse_buffers={0: True if args.graph > 0 else "recycle", 1: "single", 2: True}[args.buffers]
-                             if buffers is None else buffers,
-                             obs_dtype=torch.float32 if args.obs_dtype == "float32" else torch.uint8,
-                             placement_probe=placement_probe,
-                             placement_budget_gib="all")  # this process owns the device: the zone walk may use all of it
+        self.env = build_env(args, device, batch, env_base, size, agents, r, placement_probe, buffers, world)
         self.env.reset(seed=0)
         self.env.warm_buffers()  # zone walk + candidate timing + XCD shares here, not inside the first timed step
         tdt = {"int8": torch.int8, "int32": torch.int32, "int64": torch.int64}[args.action_dtype]
@@ -228,6 +322,27 @@ class EngineStep:
             self.env.step(self.pool[self.i % len(self.pool)], compute_obs=not self.no_obs)
             self.i += 1
 
+    def measure_held_pair(self, steps, windows=3):
+        """Secondary figure: the caller keeps step t's outputs alive until step t+1 has returned."""
+        torch = self.torch
+        rec = self.env._recycler
+        out = []
+        held = None
+        misses0 = rec.misses
+        for w in range(windows + 1):  # the first window warms up
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            for _ in range(steps):
+                nxt = self.env.step(self.pool[self.i % len(self.pool)])
+                held = nxt  # the previous outputs are dropped only now, after the next step has its buffers
+                self.i += 1
+            ev1.record()
+            torch.cuda.synchronize()
+            if w:
+                out.append(ev0.elapsed_time(ev1) / steps)
+        del held, nxt
+        return {"ms_per_step": statistics.median(out), "misses": rec.misses - misses0, "output_sets": len(rec)}
+
     def describe_buffers(self):
         pl = getattr(self.env, "placement", None) or {}
         rec = getattr(self.env, "_recycler", None)
@@ -247,6 +362,20 @@ class EngineStep:
         tuned = (f"; workgroups per XCD tuned to {pl['xcd_shares']}: observation pass {pl.get('observe_us_equal_shares')} -> "
                  f"{pl.get('observe_us_tuned_shares')} us") if pl.get("xcd_shares") else ""
         return f"{mode} as torch's allocator returned them (no zone placement){tuned}"
+
+    def placement_fields(self):
+        """roofline.placement: where the observation buffers of the timed engine lie, as structured fields -- a line at
+        0.68 of peak explains itself (spread false: no second zone found, or no walk under the policy)."""
+        pl = getattr(self.env, "placement", None) or {}
+        rec = getattr(self.env, "_recycler", None)
+        return {"spread": bool(pl.get("spread", False)), "walk_candidates": int(pl.get("candidates", 0) or 0),
+                "budget_gib": pl.get("budget_gib"), "spacer_gib_held": pl.get("spacer_gib"),
+                "policy": pl.get("policy"), "method": pl.get("method"), "pools_tried": pl.get("pools_tried"),
+                "fallback": pl.get("fallback"), "chosen": pl.get("chosen"), "observe_us": pl.get("observe_us"),
+                "probe_same_zone_us": pl.get("same_zone_us"), "probe_as_placed_us": pl.get("final_us"),
+                "xcd_shares": pl.get("xcd_shares"),
+                "output_sets": len(rec) if rec else self.nbuf,
+                "recycler": ({"hand_outs": rec.taken, "misses": rec.misses} if rec else None)}
 
     def box_store_stream_gbs(self):
         """What a bare store stream sustains on THIS box where the buffers lie (the zone walk's probe: 2 x 384 MiB,
@@ -271,7 +400,7 @@ class PipelinedStep:
                         collision_system=args.collision, on_target=args.on_target,
                         max_episode_steps=args.max_episode_steps)
         self.env = PipelinedVecPogema(gc, batch=batch, device=device, parts=parts, env_index_base=env_base, auto_reset=True,
-                                      reuse_buffers=True, placement_budget_gib="all",
+                                      reuse_buffers=True, placement_budget_gib=placement_budget(args),
                                       obs_dtype=torch.float32 if args.obs_dtype == "float32" else torch.uint8)
         self.env.reset(seed=0)
         self.env.warm_buffers()
@@ -317,7 +446,7 @@ class RolloutStep:
                         collision_system=args.collision, on_target=args.on_target,
                         max_episode_steps=args.max_episode_steps)
         self.env = VecPogema(gc, batch=batch, device=device, env_index_base=env_base, auto_reset=True,
-                             placement_budget_gib="all",
+                             placement_budget_gib=placement_budget(args),
                              obs_dtype=torch.float32 if args.obs_dtype == "float32" else torch.uint8)
         self.env.reset(seed=0)
         tdt = {"int8": torch.int8, "int32": torch.int32, "int64": torch.int64}[args.action_dtype]
@@ -366,7 +495,7 @@ class StubStep:
         pass
 
 
-def main(argv=None):
+def make_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
@@ -393,6 +522,9 @@ def main(argv=None):
                          "zone-spread pool, taken back when the caller has dropped them -- the loop drops each step's outputs "
                          "before the next step, as a policy loop does); 2 = two alternating sets (step t's tensors are "
                          "overwritten by step t+2); 1 = one set rewritten in place")
+    ap.add_argument("--placement-budget", default="default",
+                    help="HBM the engine's zone walk may hold for its 1-3 s: default = the product default (walk only on a "
+                         "device that is evidently ours, half of the free memory); half | all | a number of GiB = explicit")
     ap.add_argument("--graph", type=int, default=0, help="capture this many steps in one HIP graph and replay it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-default-placement", action="store_true",
@@ -402,7 +534,11 @@ def main(argv=None):
                     help="skip the secondary figures (two pipelined engines; K-step rollout launches)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)  # tests only, see StubStep
-    args = ap.parse_args(argv)
+    return ap
+
+
+def main(argv=None):
+    args = make_parser().parse_args(argv)
     if args.gpus < 1 or args.steps < 1 or args.windows < 1:
         raise SystemExit("--gpus, --steps and --windows must be >= 1")
     if args.graph > 0 and args.steps % args.graph:
@@ -418,6 +554,8 @@ def main(argv=None):
         if world != args.gpus:
             raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; they must agree")
 
+    fingerprint = box_fingerprint() if rank == 0 else None  # plain sysfs reads, before anything touches the GPU
+
     import torch
     import torch.distributed as dist
 
@@ -429,13 +567,23 @@ def main(argv=None):
     else:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a HIP device; there is no CPU fallback for the product path")
-        if local_rank >= torch.cuda.device_count():
+        rehearsal = share_device() and world > torch.cuda.device_count()
+        if local_rank >= torch.cuda.device_count() and not rehearsal:
             raise SystemExit(f"bench.py: rank {rank} wants device {local_rank}, the box has {torch.cuda.device_count()}")
-        torch.cuda.set_device(local_rank)
-        device = torch.device("cuda", local_rank)
-        if world > 1:
+        dev_index = local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(dev_index)
+        device = torch.device("cuda", dev_index)
+        if world > 1 or os.environ.get("PGX_BENCH_FORCE_DIST", "0") not in ("", "0"):
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("nccl", device_id=device)
+            if rehearsal:  # RCCL refuses two ranks on one device: gloo, host tensors (comm_device)
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                if "MASTER_PORT" not in os.environ:  # PGX_BENCH_FORCE_DIST without a launcher
+                    os.environ.update(MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
+                dist.init_process_group("nccl", device_id=device)
+    use_dist = dist.is_initialized()
+    rehearsal = (not args.stub) and share_device() and world > torch.cuda.device_count()
+    comm_device = torch.device("cpu") if (args.stub or rehearsal) else device  # where the clock / kernel-time tensors live
 
     from pogema_amd.sharding import shard_bounds
     per_gpu, size, agents, r = WORKLOADS[args.workload]
@@ -454,14 +602,14 @@ def main(argv=None):
 
     def barrier():
         sync()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         sync()
 
     def reduce_max(x: float) -> float:
-        if world == 1:
+        if not use_dist:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=device)
+        t = torch.tensor([x], dtype=torch.float64, device=comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -485,7 +633,7 @@ def main(argv=None):
         return walls, kernel
 
     default_ms = None
-    step = StubStep(rank) if args.stub else EngineStep(args, rank, device, batch, env_base, size, agents, r)
+    step = StubStep(rank) if args.stub else EngineStep(args, rank, device, batch, env_base, size, agents, r, world=world)
     warm = args.warmup if args.graph <= 0 else -(-args.warmup // args.graph) * args.graph
     if warm:
         step.run(warm)
@@ -493,8 +641,8 @@ def main(argv=None):
     elapsed = statistics.median(walls)
     kernel_ms = statistics.median(kernel)
     per_rank_kernel = [kernel_ms]
-    if world > 1:
-        t = torch.tensor([kernel_ms], dtype=torch.float64, device=device)
+    if use_dist:
+        t = torch.tensor([kernel_ms], dtype=torch.float64, device=comm_device)
         parts = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(parts, t)
         per_rank_kernel = [float(p.item()) for p in parts]
@@ -516,6 +664,11 @@ def main(argv=None):
             and not args.no_obs and args.buffers != 1):
         n = min(args.steps, 1000)
         extra_errors = {}
+        if args.buffers == 0 and getattr(step.env, "_recycler", None):
+            try:
+                extras["held_pair"] = step.measure_held_pair(n)
+            except Exception as exc:  # noqa: BLE001
+                extra_errors["held_pair"] = repr(exc)
         if batch % 2 == 0:
             try:  # a secondary figure must never cost the headline line
                 ps = PipelinedStep(args, rank, device, batch, env_base, size, agents, r)
@@ -554,16 +707,22 @@ def main(argv=None):
             except Exception:
                 traffic = None
         # BASELINE.json's metric label only for BASELINE.json's workload as the product runs it: configs[2], float32,
-        # 8192 envs on every GPU, one launch per step into two alternating buffers, observations written
+        # 8192 envs on every GPU, one launch per step, observations written, the DEFAULT output allocator
+        # (reuse_buffers='recycle': three output sets handed out in turn; this loop drops every step's outputs before the
+        # next step, so no hand-out ever misses -- roofline.placement.recycler; the caller who HOLDS (obs, next_obs) is
+        # the secondary figure `held_pair`) -- ADVICE r2 / r3
         headline = (args.workload == "cfg2" and args.obs_dtype == "float32" and not args.stub and batch == per_gpu
-                    and args.global_batch == 0 and args.buffers == 0 and args.graph == 0 and not args.no_obs)
+                    and args.global_batch == 0 and args.buffers == 0 and args.graph == 0 and not args.no_obs
+                    and not rehearsal)
         variant = "".join([f", {batch} envs per GPU" if args.global_batch == 0 else f", global batch {total_envs}",
                            {0: "", 1: ", one output set rewritten in place", 2: ", two alternating output sets"}[args.buffers],
                            f", hipGraph of {args.graph} steps" if args.graph > 0 else "",
                            ", NO observation write (diagnostic)" if args.no_obs else ""])
         line = {
             "metric": "agent-steps/sec (whole node), 64-agent 64x64 grid, batch=8192 envs" if headline
-                      else f"{'STUB (not a measurement) ' if args.stub else ''}agent-steps/sec (whole node), "
+                      else f"{'STUB (not a measurement) ' if args.stub else ''}"
+                           f"{f'REHEARSAL ({world} ranks share {torch.cuda.device_count()} device(s); not a measurement) ' if rehearsal else ''}"
+                           f"agent-steps/sec (whole node), "
                            f"workload {args.workload}, obs {args.obs_dtype}{variant}",
             "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
@@ -577,10 +736,21 @@ def main(argv=None):
                        "max_episode_steps": args.max_episode_steps, "obs_dtype": args.obs_dtype,
                        "action_dtype": args.action_dtype, "envs_per_gpu": batch, "global_batch": total_envs,
                        "sharding": f"batch-sharded x{world}, no collective",
+                       "rehearsal": bool(rehearsal),
+                       "process_group": (dist.get_backend() if use_dist else None),
                        "launch": f"hipGraph of {args.graph} steps" if args.graph > 0 else "one pgx_step launch per step",
                        "obs_buffers": step.describe_buffers()},
             "roofline": {"bound": "hbm" if (args.buffers != 1 or alg_bytes > (200 << 20)) else "hbm (output tensor rewritten in place: largely Infinity-Cache resident)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": (None if traffic is None else
+                                            "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an "
+                                            "EARLIER run of this workload (calibrated per MI355X_MICROARCH.md; the per-round "
+                                            "summaries are profiles/rN/cfg*_pmc_summary.json) -- a looked-up figure, not measured "
+                                            "by this process"),
+                         "peak_note": "8000 GB/s = HBM3E spec (MI355X_MICROARCH.md); the guide's 6.29 TB/s is a float4 COPY "
+                                      "(read + write); this kernel is a write-only stream, and bare store streams reach "
+                                      "6.7-7.0 TB/s on this pool (DESIGN.md 4b, roofline.box_store_stream_gbs)",
+                         "placement": None if args.stub else step.placement_fields(),
                          "kernel": "pgx::step_kernel", "kernel_ms": kernel_ms, "kernel_ms_per_rank": per_rank_kernel,
                          "kernel_ms_windows": kernel,
                          "default_placement_kernel_ms": default_ms,
@@ -604,14 +774,22 @@ def main(argv=None):
                      what="pgx_rollout: 64 steps per launch with the actions given up front, observations into a ring of "
                           "obs_slots tensors (>= 1 GiB in total); bit-identical with 64 pgx_step calls; HIP events around the "
                           "launches")
+        if "held_pair" in extras:
+            e = extras["held_pair"]
+            e.update(value=batch * agents / (e["ms_per_step"] * 1e-3), unit="agent-steps/s",
+                     frac=alg_bytes / (e["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     what="the headline engine stepped by a caller that HOLDS the previous step's outputs while taking the "
+                          "next (obs, next_obs pairs, as a replay-buffer writer does): two of the three recycled output sets "
+                          "are out at any time; `misses` = hand-outs that fell back to fresh torch tensors")
         if extras:
             line["secondary"] = extras
+        line["box"] = fingerprint
         if world == 1 and not args.no_cpu_baseline and not args.stub:
             line["cpu_baseline"] = cpu_baseline(size, agents, r, args.collision, args.density, args.max_episode_steps,
                                                 args.cpu_seconds)
         print(json.dumps(line), flush=True)
     step.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

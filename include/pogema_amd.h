@@ -214,6 +214,27 @@ int pgx_step(pgx_env* env, const void* actions, int action_dtype, void* obs, flo
 int pgx_xcd_shares(pgx_env* env, int32_t* shares);
 int pgx_xcd_tune(pgx_env* env, void* obs, void* obs_alt, int32_t rounds, float* us_equal, float* us_tuned, void* stream);
 
+/* The launch shape pgx_step (for_rollout = 0) or pgx_rollout (1) uses for this handle -- read-only, for tests and
+ * benchmarks that must show they ran the SAME kernel variant (tests/test_fullsize_gpu.py asserts that its parity
+ * engines and bench.py's engine agree for every BASELINE config) and for reading a profile: which template instance
+ * (lanes_per_env, multi_wave, p16), how many waves per workgroup and environments per wave, which store flavour.
+ * Chosen once in pgx_create from (batch, num_agents, map, obs_radius, obs_dtype) and the PGX_* tuning overrides. */
+typedef struct pgx_geometry {
+    int32_t lanes_per_env;  /* G: lanes of a wave one environment occupies (power of two; 64 when multi_wave)       */
+    int32_t waves;          /* waves per workgroup                                                                   */
+    int32_t envs_per_wave;  /* environments per single-wave workgroup (1 when multi_wave)                            */
+    int32_t multi_wave;     /* 1: one environment per workgroup of `waves` waves (num_agents > 64, or helper waves)  */
+    int32_t p16;            /* 1: window side <= 16, packed 16-bit row masks                                         */
+    int32_t stagger;        /* cohort stagger of the single-wave kernel (0 = off)                                    */
+    int32_t store_policy;   /* observation stores: 0 plain, 1 nontemporal, 2 sc1 write-through                       */
+    int32_t state_stores;   /* when the small per-step result stores are issued: 0 at once, 1 after the LDS barrier, 2 after the stream */
+    int32_t grid;           /* workgroups launched                                                                   */
+    int32_t lds_bytes;      /* dynamic LDS per workgroup                                                             */
+    int32_t for_rollout;    /* echo of the argument                                                                  */
+    int32_t reserved0;
+} pgx_geometry;
+int pgx_get_geometry(const pgx_env* env, int32_t for_rollout, pgx_geometry* out);
+
 /* K steps in ONE launch: the same as `steps` consecutive pgx_step calls with actions[t] -- bit for bit, state and outputs
  * -- for callers that have the actions up front (executing MAPF plans, scripted or random policies, replaying recorded
  * episodes): upstream, the `for t in range(K): env.step(actions[t])` loop around `Pogema.step`.  Every workgroup takes its

@@ -52,7 +52,7 @@ EXPORTED_SYMBOLS = (
     "pgx_reset_from_state", "pgx_reset_random", "pgx_regenerate", "pgx_regenerate_failures", "pgx_get_map", "pgx_step", "pgx_observe", "pgx_set_metrics_buffers", "pgx_get_state", "pgx_generate", "pgx_place_agents",
     "pgx_snapshot_bytes", "pgx_save_snapshot", "pgx_load_snapshot", "pgx_time_observe", "pgx_bad_action_count",
     "pgx_buffers_create", "pgx_buffers_ptr", "pgx_buffers_get_info", "pgx_buffers_destroy", "pgx_set_targets",
-    "pgx_np_streams", "pgx_np_streams_host", "pgx_np_generate", "pgx_np_generate_host", "pgx_rollout", "pgx_buffers_stride", "pgx_buffers_drop", "pgx_xcd_shares", "pgx_xcd_tune", "pgx_buffers_create_at", "pgx_time_observe_pair", "pgx_buffers_va_reserved",
+    "pgx_np_streams", "pgx_np_streams_host", "pgx_np_generate", "pgx_np_generate_host", "pgx_rollout", "pgx_buffers_stride", "pgx_buffers_drop", "pgx_xcd_shares", "pgx_xcd_tune", "pgx_buffers_create_at", "pgx_time_observe_pair", "pgx_buffers_va_reserved", "pgx_get_geometry",
 )
 
 
@@ -66,6 +66,11 @@ class PgxBuffersInfo(C.Structure):
     _fields_ = [("bytes", C.c_int64), ("count", C.c_int32), ("spread", C.c_int32), ("candidates", C.c_int32),
                 ("reserved0", C.c_int32), ("same_zone_us", C.c_float), ("final_us", C.c_float), ("spacer_gib", C.c_double),
                 ("buffer_gbs", C.c_float), ("reserved1", C.c_float)]
+
+
+class PgxGeometry(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("lanes_per_env", "waves", "envs_per_wave", "multi_wave", "p16", "stagger",
+                                          "store_policy", "state_stores", "grid", "lds_bytes", "for_rollout", "reserved0")]
 
 
 class PgxRolloutIO(C.Structure):
@@ -142,6 +147,8 @@ def load() -> C.CDLL:
     lib.pgx_np_generate_host.restype = C.c_int
     lib.pgx_xcd_tune.argtypes = [vp, vp, vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), vp]
     lib.pgx_xcd_tune.restype = C.c_int
+    lib.pgx_get_geometry.argtypes = [vp, i32, C.POINTER(PgxGeometry)]
+    lib.pgx_get_geometry.restype = C.c_int
     lib.pgx_xcd_shares.argtypes = [vp, vp]
     lib.pgx_xcd_shares.restype = C.c_int
     lib.pgx_buffers_drop.argtypes = [vp, i32]

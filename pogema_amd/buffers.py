@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import atexit
 import collections
+import contextlib
 import ctypes as C
 import os
 import threading
@@ -125,53 +126,108 @@ class ZoneBuffers:
         _lib.check(self._lib.pgx_buffers_drop(self._handle, int(index)))
 
 
+@contextlib.contextmanager
+def walk_lock(device_index: int, wait: bool = False):
+    """One zone walk per DEVICE at a time, across processes: an exclusive flock on a per-device file in the temp dir
+    (keyed by the device's UUID / PCI bus id, so that processes with different HIP_VISIBLE_DEVICES agree).  Yields True
+    when this process holds the lock.  wait=False (the default policy): a busy lock means another process is walking the
+    device right now, i.e. the device is shared -- yields False at once and the caller skips its walk (workers
+    that start together must not each hold half of the free memory).  wait=True (an explicit budget): block until free,
+    because two concurrent walks perturb each other's timings.  Never raises: without a usable lock file it yields True."""
+    import fcntl
+    import tempfile
+    fd, held = None, True
+    try:
+        try:
+            props = torch.cuda.get_device_properties(device_index)
+            ident = str(getattr(props, "uuid", None) or getattr(props, "pci_bus_id", None) or device_index)
+        except Exception:  # noqa: BLE001
+            ident = str(device_index)
+        ident = "".join(ch if ch.isalnum() else "_" for ch in ident)
+        path = os.path.join(tempfile.gettempdir(), f"pgx_zone_walk_{ident}.lock")
+        fd = os.open(path, os.O_CREAT | os.O_RDWR, 0o666)
+        try:
+            fcntl.flock(fd, fcntl.LOCK_EX | (0 if wait else fcntl.LOCK_NB))
+        except BlockingIOError:
+            held = False
+    except OSError:
+        fd = None  # no lock file (read-only temp dir ...): behave as before
+    try:
+        yield held
+    finally:
+        if fd is not None:
+            try:
+                if held:
+                    fcntl.flock(fd, fcntl.LOCK_UN)
+            finally:
+                os.close(fd)
+
+
 class ParkedBuffers:
     """Process-wide shelf for the observation buffers of CLOSED environments (reuse_buffers='recycle').
 
     Picking zone-spread buffers costs a walk of 1-3 s, and a pool's address ranges are never handed back to the driver
     (DESIGN.md 4b), so a process that creates environments in a loop -- sweeps, test suites, evaluation workers --
-    would pay the walk and leak address space every time.  Instead `VecPogema.close()` parks the buffers nobody references
-    any more, still mapped, and the next environment with the same observation tensor on the same device takes them over
-    without a walk.  At most PGX_POOL_CACHE_MB (default 6144; 0 = off) stay parked, oldest first out; `clear()` empties
-    the shelf (the memory is then released with the last reference, as always)."""
+    would pay the walk and leak address space every time.  Instead `VecPogema.close()` parks the zone-spread buffers
+    nobody references any more, still mapped, and the next environment with the same observation tensor on the same
+    device takes them over without a walk.
+
+    Only WHOLE sets are kept: a set is exactly the number of buffers an environment of that shape claims, so
+    whatever sits on the shelf is usable; a close() that can return fewer (the caller still holds a tensor) parks
+    nothing, a set larger than the limit is not parked at all, and eviction drops whole sets, oldest first.  The limit
+    is PGX_POOL_CACHE_MB (default 2560: one set of configs[2]; 0 = off) -- memory a caller does NOT get back by closing
+    an environment until `clear()` (= `pogema_amd.release_cached_buffers()`, `VecPogema.close(release=True)`) or exit."""
 
     _lock = threading.Lock()
-    _shelf = collections.OrderedDict()  # key -> [(tensor, placement info), ...]
+    _shelf = collections.OrderedDict()  # key -> [(tensors of one set, placement info), ...]
 
     @staticmethod
     def limit_bytes() -> int:
-        return int(os.environ.get("PGX_POOL_CACHE_MB", "6144")) << 20
+        return int(os.environ.get("PGX_POOL_CACHE_MB", "2560")) << 20
+
+    @staticmethod
+    def _set_bytes(tensors) -> int:
+        return sum(t.numel() * t.element_size() for t in tensors)
 
     @classmethod
-    def _bytes(cls) -> int:
-        return sum(t.numel() * t.element_size() for items in cls._shelf.values() for t, _ in items)
-
-    @classmethod
-    def park(cls, key, tensors, info) -> int:
-        limit = cls.limit_bytes()
-        if limit <= 0 or not tensors:
-            return 0
+    def bytes_parked(cls) -> int:
         with cls._lock:
-            cls._shelf.setdefault(key, []).extend((t, dict(info)) for t in tensors)
+            return sum(cls._set_bytes(ts) for sets in cls._shelf.values() for ts, _ in sets)
+
+    @classmethod
+    def park(cls, key, tensors, info, set_size: int) -> bool:
+        """Shelve `tensors` as one set of exactly `set_size` buffers (surplus buffers are simply released); False -- and
+        nothing kept -- when fewer were returned, the shelf is off, or the set alone exceeds the limit."""
+        limit = cls.limit_bytes()
+        tensors = list(tensors)[:set_size]
+        if limit <= 0 or set_size < 1 or len(tensors) < set_size or cls._set_bytes(tensors) > limit:
+            return False
+        with cls._lock:
+            cls._shelf.setdefault(key, []).append((tensors, dict(info)))
             cls._shelf.move_to_end(key)
-            while cls._shelf and cls._bytes() > limit:  # oldest key first, one buffer at a time
+            total = sum(cls._set_bytes(ts) for sets in cls._shelf.values() for ts, _ in sets)
+            while total > limit:  # whole sets, oldest key first, oldest set of that key first (never the one just parked)
                 old = next(iter(cls._shelf))
-                cls._shelf[old].pop(0)
+                gone, _ = cls._shelf[old].pop(0)
+                total -= cls._set_bytes(gone)
                 if not cls._shelf[old]:
                     del cls._shelf[old]
-            return len(cls._shelf.get(key, ()))
+            return True
 
     @classmethod
     def claim(cls, key, n):
-        """n parked buffers for `key` as ([tensors], info of the first one), or None when fewer are parked."""
+        """A parked set of n buffers for `key` as ([tensors], its placement info), or None."""
         with cls._lock:
-            items = cls._shelf.get(key)
-            if not items or len(items) < n:
+            sets = cls._shelf.get(key)
+            if not sets:
                 return None
-            taken = [items.pop() for _ in range(n)]
-            if not items:
-                del cls._shelf[key]
-            return [t for t, _ in taken], taken[0][1]
+            for i in range(len(sets) - 1, -1, -1):
+                if len(sets[i][0]) == n:
+                    tensors, info = sets.pop(i)
+                    if not sets:
+                        del cls._shelf[key]
+                    return tensors, info
+            return None
 
     @classmethod
     def clear(cls):
@@ -180,6 +236,49 @@ class ParkedBuffers:
 
 
 atexit.register(ParkedBuffers.clear)  # release parked pools while the HIP runtime is still up, not during module teardown
+
+
+def storage_count_hook():
+    """`torch._C._storage_Use_Count` if this torch build has it AND it still means what RecyclingOutputs relies on -- the
+    number of live tensors (views included) sharing a storage: +1 per extra tensor or view, back down when they die.  The
+    hook is private API, so its meaning is re-checked on a tiny CPU tensor (once per process) instead of trusted by
+    version; None -- with one loud warning -- when it is missing or behaves differently, and reuse_buffers='recycle' then
+    degrades to fresh tensors per step (correct, slower).  tests/test_buffer_choice.py fails when that happens, so a torch
+    upgrade that changes the hook is noticed on the CPU."""
+    global _HOOK
+    if _HOOK is not _UNSET:
+        return _HOOK
+    hook, why = getattr(torch._C, "_storage_Use_Count", None), None
+    if hook is None:
+        why = "torch._C._storage_Use_Count is missing"
+    else:
+        try:
+            master = torch.empty(8, dtype=torch.uint8)
+            cdata = master.untyped_storage()._cdata
+            base = hook(cdata)
+            alias = master.detach()
+            one = hook(cdata)
+            view = alias[2:4].view(torch.int16)
+            two = hook(cdata)
+            del alias
+            still = hook(cdata)   # the view keeps the storage referenced
+            del view
+            back = hook(cdata)
+            if not (one == base + 1 and two == base + 2 and still == base + 1 and back == base):
+                why = f"torch._C._storage_Use_Count no longer counts tensors per storage ({base}, {one}, {two}, {still}, {back})"
+        except Exception as exc:  # noqa: BLE001
+            why = f"torch._C._storage_Use_Count self-test raised {exc!r}"
+    if why is not None:
+        import warnings
+        warnings.warn(f"pogema_amd: {why} in torch {torch.__version__}; reuse_buffers='recycle' falls back to allocating "
+                      f"fresh output tensors per step", RuntimeWarning, stacklevel=2)
+        hook = None
+    _HOOK = hook
+    return hook
+
+
+_UNSET = object()
+_HOOK = _UNSET
 
 
 class RecyclingOutputs:
@@ -194,17 +293,19 @@ class RecyclingOutputs:
     consumer on ANOTHER stream must synchronise before dropping its reference (torch: Tensor.record_stream).
 
     "Nobody references it" is read off the storages' reference counts (torch._C._storage_Use_Count, 0.15 us each); a
-    handed-out tensor is `master.detach()` (1 us) -- together half the host time of five torch.empty calls.  `available()`
-    says whether this torch build has the hook; without it the caller simply allocates fresh tensors."""
+    handed-out tensor is `master.detach()` (1 us) -- together half the host time of five torch.empty calls.  The hook is
+    private torch API: `storage_count_hook()` verifies its meaning before it is used, `available()` says whether it
+    passed; without it the caller allocates fresh tensors (and has been warned)."""
 
     @staticmethod
     def available() -> bool:
-        return hasattr(torch._C, "_storage_Use_Count")
+        return storage_count_hook() is not None
 
-    def __init__(self, obs_tensors, batch: int, agents: int):
+    def __init__(self, obs_tensors, batch: int, agents: int, zone_ptrs=()):
         if not self.available():
-            raise RuntimeError("torch._C._storage_Use_Count is missing in this torch build")
-        self._count = torch._C._storage_Use_Count
+            raise RuntimeError("torch._C._storage_Use_Count is missing or changed its meaning in this torch build")
+        self._count = storage_count_hook()
+        self._zone_ptrs = frozenset(int(p) for p in zone_ptrs)  # observation buffers that come from a zone pool
         dev = obs_tensors[0].device
         n = batch * agents
         self._sets = []
@@ -236,10 +337,11 @@ class RecyclingOutputs:
         return sum(self._is_idle(i) for i in range(len(self._sets)))
 
     def retire(self):
-        """The observation buffers nobody outside the pool references any more, removed from circulation (for
-        ParkedBuffers when the environment closes); sets that are still referenced stay and die with their last user."""
+        """The ZONE-POOL observation buffers nobody outside the pool references any more, removed from circulation (for
+        ParkedBuffers when the environment closes); sets that are still referenced stay and die with their last user, and
+        buffers from torch's own allocator simply go back to it."""
         idle = [i for i in range(len(self._sets)) if self._is_idle(i)]
-        out = [self._sets[i][0][0] for i in idle]
+        out = [self._sets[i][0][0] for i in idle if self._sets[i][0][0].data_ptr() in self._zone_ptrs]
         for i in reversed(idle):
             del self._sets[i]
             del self._idle[i]

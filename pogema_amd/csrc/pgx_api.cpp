@@ -916,6 +916,24 @@ int pgx_xcd_shares(pgx_env* e, int32_t* shares) {
     return PGX_OK;
 }
 
+int pgx_get_geometry(const pgx_env* e, int32_t for_rollout, pgx_geometry* out) {
+    if (!e || !out) return fail(PGX_E_INVALID, "pgx_get_geometry: null argument");
+    const pgx::StepGeometry& g = for_rollout ? e->geo_roll : e->geo;
+    out->lanes_per_env = g.G;
+    out->waves = g.waves;
+    out->envs_per_wave = g.epw;
+    out->multi_wave = g.multi_wave ? 1 : 0;
+    out->p16 = g.p16 ? 1 : 0;
+    out->stagger = g.stagger;
+    out->store_policy = g.store_policy;
+    out->state_stores = g.state_stores;
+    out->grid = g.grid;
+    out->lds_bytes = (int32_t)g.lds_bytes;
+    out->for_rollout = for_rollout ? 1 : 0;
+    out->reserved0 = 0;
+    return PGX_OK;
+}
+
 int pgx_debug_timestamps(pgx_env* e, unsigned long long* host_out, int64_t max_elems) {
     if (!e || !host_out) return fail(PGX_E_INVALID, "pgx_debug_timestamps: null argument");
     if (!e->dbg) return fail(PGX_E_STATE, "diagnostic stamps not enabled (PGX_FLAGS bit 2)");

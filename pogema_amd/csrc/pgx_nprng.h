@@ -20,7 +20,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)  // hipcc (host + device); a plain C++ compiler sees host-only inlines
 #define PGX_NP_HD __host__ __device__ inline
 #else
 #define PGX_NP_HD static inline

@@ -41,8 +41,13 @@ def gather_to_host(local: torch.Tensor, global_batch: int, dst: int = 0) -> Opti
     """Host-side gather of per-rank batch slices (dim 0) into one CPU tensor on rank `dst`."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return local.detach().cpu()
+    if local.dim() == 0:
+        raise ValueError("gather_to_host gathers along the batch axis (dim 0)")
     world, rank = dist.get_world_size(), dist.get_rank()
     host = local.detach().cpu().contiguous()
+    as_bool = host.dtype == torch.bool  # gloo has no bool: flags travel as bytes
+    if as_bool:
+        host = host.view(torch.uint8)
     group = _host_group()
     counts = [shard_bounds(global_batch, world, r)[1] for r in range(world)]
     if host.shape[0] != counts[rank]:
@@ -54,7 +59,8 @@ def gather_to_host(local: torch.Tensor, global_batch: int, dst: int = 0) -> Opti
     if rank == dst:
         parts = [torch.empty_like(host) for _ in range(world)]
         dist.gather(host, gather_list=parts, dst=dst, group=group)
-        return torch.cat([part[:c] for part, c in zip(parts, counts)], dim=0)
+        whole = torch.cat([part[:c] for part, c in zip(parts, counts)], dim=0)
+        return whole.view(torch.bool) if as_bool else whole
     dist.gather(host, gather_list=None, dst=dst, group=group)
     return None
 

@@ -69,10 +69,20 @@ class VecPogema:
                   tensors are handed to ANOTHER PROCESS through CUDA IPC: pool buffers are HIP virtual-memory mappings,
                   which hipIpcGetMemHandle does not export.)
     Or hand step() your own buffers with `out=`.
-    The buffers are picked on first use: a zone walk that holds up to `placement_budget_gib` of HBM for 1-2 s and
-    synchronises the device.  Call `warm_buffers()` after reset() to have that happen at a moment of your choosing
-    (required before capturing step() in a HIP graph); if the walk fails (another process took the memory meanwhile)
-    the buffers come from torch's allocator and `placement["fallback"]` says why.
+    The buffers are picked on first use.  For observation tensors >= 128 MiB that MAY include a zone walk: 1-3 s during
+    which up to `placement_budget_gib` of HBM is held, the device is synchronised and torch's cache is emptied.  Who gets
+    one (`placement_budget_gib`, `placement["policy"]` says what happened):
+      None (default)  only a process that evidently has the device to itself: >= 90 % of its memory free AND no other
+                      process walking it right now (a per-device file lock) -- then half of the free memory.  On a
+                      shared or already loaded device there is NO walk, no timing allocations, no cache flush: the
+                      buffers are plain torch memory (recycled all the same; 15-25 % slower steps on configs[2]).
+      "half" / a number of GiB / "all"   an explicit request: walk with that budget wherever you are
+                      ("all" = everything but the engine's 10 % reserve: a process that owns the device).
+      0               never walk.
+    Call `warm_buffers()` after reset() to have the walk happen at a moment of your choosing (required before capturing
+    step() in a HIP graph); if it fails (another process took the memory meanwhile) the buffers come from torch's
+    allocator and `placement["fallback"]` says why.  `close()` keeps one set of zone buffers mapped for the next
+    environment of the same shape (buffers.ParkedBuffers, PGX_POOL_CACHE_MB); `close(release=True)` does not.
 
     `semantics`: switches for the three low-confidence recollections of the reference (pogema_amd/semantics.py).
     Seeds: `reset(seed)` selects the instances (maps, starts, targets); the lifelong target stream and the
@@ -130,10 +140,12 @@ class VecPogema:
         self.semantics = semantics if semantics is not None else Semantics.from_env()
         # placement probe of the double-buffered observation tensors (reuse_buffers=True); PGX_PLACEMENT=0 disables
         self.placement_probe = (os.environ.get("PGX_PLACEMENT") != "0") if placement_probe is None else bool(placement_probe)
-        # HBM the zone walk may hold for its ~1-2 s (buffers.ZoneBuffers): None = half of the free memory (safe on a
-        # device shared with other processes), "all" = everything but the engine's 10 % reserve (a process that owns
-        # the device: bench.py), a number = GiB, 0 = no walk
+        # HBM the zone walk may hold for its ~1-3 s: see the class docstring and _walk_policy()
+        if not (placement_budget_gib is None or placement_budget_gib in ("all", "half") or
+                (isinstance(placement_budget_gib, (int, float)) and placement_budget_gib >= 0)):
+            raise ValueError("placement_budget_gib must be None, 'half', 'all' or a number of GiB >= 0")
         self.placement_budget_gib = placement_budget_gib
+        self._zone_ptrs = set()   # data_ptr() of the observation buffers that come from a zone pool
         # float32 is the reference's observation dtype (gymnasium Box float32) and the default; torch.uint8 writes
         # the same 0/1 planes one byte per cell (4x fewer HBM bytes per step) for callers that cast on their side
         if obs_dtype not in _lib.OBS_DTYPES:
@@ -164,11 +176,21 @@ class VecPogema:
         _lib.check(self._lib.pgx_set_metrics_buffers(self._handle, self.metrics.data_ptr(), self.episode_done.data_ptr()))
 
     # ------------------------------------------------------------------------------------------
-    def close(self):
+    def close(self, release: bool = False):
+        """Destroys the engine.  Zone-spread observation buffers nobody references any more are kept mapped for the next
+        environment of this shape (one set, see buffers.ParkedBuffers); `release=True` gives everything back now --
+        this environment's buffers and whatever earlier ones left on the shelf."""
         if getattr(self, "_handle", None) is not None and self._handle.value:
-            self._park_buffers()
+            if not release:
+                self._park_buffers()
+            self._recycler = None
+            self._bufs = None
+            self._rollout_pools = {}
             self._lib.pgx_destroy(self._handle)
             self._handle = C.c_void_p()
+        if release:
+            from .buffers import ParkedBuffers
+            ParkedBuffers.clear()
 
     def _shelf_key(self):
         return (self.device_index, tuple(self.obs_shape), self.obs_dtype)
@@ -177,11 +199,12 @@ class VecPogema:
         """reuse_buffers='recycle': zone-spread observation buffers that nobody references any more go to the process-wide
         shelf (buffers.ParkedBuffers) for the next environment of this shape instead of being unmapped."""
         rec, pl = getattr(self, "_recycler", None), getattr(self, "placement", None) or {}
-        if rec and str(pl.get("method", "")).startswith("pgx_buffers"):
+        if rec and self._zone_ptrs:
             from .buffers import ParkedBuffers
             try:
                 torch.cuda.current_stream(self.device).synchronize()  # nothing of this engine may still be writing
-                ParkedBuffers.park(self._shelf_key(), rec.retire(), pl)
+                n = self._recycle_sets(int(np.prod(self.obs_shape)) * (4 if self.obs_dtype == torch.float32 else 1))
+                ParkedBuffers.park(self._shelf_key(), rec.retire(), pl, n)  # only zone-pool buffers, only a whole set
             except Exception:
                 pass
 
@@ -204,6 +227,13 @@ class VecPogema:
 
     def get_num_agents(self):
         return self.num_agents
+
+    def geometry(self, for_rollout: bool = False) -> dict:
+        """The launch shape of step() (or rollout()): pgx_get_geometry as a dict -- lanes_per_env, waves, envs_per_wave,
+        multi_wave, p16, stagger, store_policy, state_stores, grid, lds_bytes."""
+        g = _lib.PgxGeometry()
+        _lib.check(self._lib.pgx_get_geometry(self._handle, 1 if for_rollout else 0, C.byref(g)))
+        return {n: int(getattr(g, n)) for n, _ in g._fields_ if n not in ("for_rollout", "reserved0")}
 
     def regenerate_failures(self) -> int:
         """Envs that kept their previous instance because no fresh one could be placed (auto_reset='regenerate')."""
@@ -428,12 +458,48 @@ class VecPogema:
     # alternating 190 MB buffers exceed the cache together and gain 2-3 % from the pool.
     PLACEMENT_MIN_BYTES = int(os.environ.get("PGX_ZONE_MIN_MB", "128")) << 20
 
+    EXCLUSIVE_FREE_FRACTION = 0.90
+
+    def _walk_policy(self):
+        """-> (GiB the zone walk may hold; 0 = no walk, why, explicit?) -- class docstring, `placement_budget_gib`."""
+        from .buffers import ZoneBuffers
+        b = self.placement_budget_gib
+        free, total = torch.cuda.mem_get_info(self.device_index)
+        half = min(ZoneBuffers.ALL_GIB, 0.5 * free / float(1 << 30))
+        if b == "all":
+            return float(os.environ.get("PGX_ZONE_SPACER_GIB", ZoneBuffers.ALL_GIB)), "explicit: all", True
+        if b == "half":
+            return half, "explicit: half of the free memory", True
+        if b is not None:
+            return float(b), f"explicit: {float(b):g} GiB", True
+        env = os.environ.get("PGX_ZONE_SPACER_GIB")
+        if env is not None:
+            return float(env), f"PGX_ZONE_SPACER_GIB={env}", True
+        if free < self.EXCLUSIVE_FREE_FRACTION * total:
+            return 0.0, (f"no walk: device {self.device_index} is shared or already loaded ({100.0 * free / total:.0f} % of its "
+                         f"memory free, < {100 * self.EXCLUSIVE_FREE_FRACTION:.0f} %)"), False
+        return half, "auto: the device looks exclusively ours -> half of the free memory", False
+
     def _pick_obs_buffers(self, n: Optional[int] = None):
         obs_bytes = int(np.prod(self.obs_shape)) * (4 if self.obs_dtype == torch.float32 else 1)
         if n is None:
             n = 1 if self.single_buffer else 2
         if not self.placement_probe or obs_bytes < self.PLACEMENT_MIN_BYTES:
             return self._plain_obs_buffers(n)
+        from .buffers import walk_lock
+        budget, why, explicit = self._walk_policy()
+        if budget <= 0.0:
+            return self._plain_obs_buffers(n, policy=why)
+        with walk_lock(self.device_index, wait=explicit) as mine:
+            if not mine:  # somebody else is walking this device right now: it is not ours alone
+                return self._plain_obs_buffers(n, policy=f"no walk: another process is walking device {self.device_index}")
+            self._budget_now = budget
+            bufs = self._pick_obs_buffers_walk(n, obs_bytes)
+            if self.placement is not None:
+                self.placement.setdefault("policy", why)
+            return bufs
+
+    def _pick_obs_buffers_walk(self, n: int, obs_bytes: int):
         # The walk's verdict does not always carry over to the real buffers (halves may straddle a boundary), and some
         # boxes show no zones at all: ask the pool for two buffers more than needed, time the observation stream itself
         # into each of them and into a few buffers as torch's allocator hands them out, keep the fastest n and give
@@ -470,6 +536,7 @@ class VecPogema:
         other = [c for c in cands if c[2] != "zone"]
         picks = choose_buffers([c[0] for c in zone], [c[0] for c in other], n)
         chosen = [(zone if kind == "zone" else other)[i] for kind, i in picks]
+        self._zone_ptrs = {c[3].data_ptr() for c in chosen if c[2] == "zone"}
         self.placement.update(chosen=[c[2] for c in chosen], observe_us=[round(c[0], 1) for c in chosen],
                               observe_us_zone=[round(c[0], 1) for c in zone],
                               observe_us_torch_best=round(min((c[0] for c in other), default=0.0), 1))
@@ -482,6 +549,7 @@ class VecPogema:
             self.placement.update(observe_pair_us=round(pair_chosen, 1), observe_pair_us_torch=round(pair_plain, 1))
             if pair_plain < 0.98 * pair_chosen:
                 chosen = other[:2]
+                self._zone_ptrs = set()
                 self.placement.update(chosen=[c[2] for c in chosen], observe_us=[round(c[0], 1) for c in chosen])
         kept = {(c[4], c[5]) for c in chosen if c[2] == "zone"}
         result = [c[3] for c in chosen]
@@ -498,11 +566,14 @@ class VecPogema:
     def _zone_pool(self, count: int, skip_gib: float = 0.0):
         from .buffers import ZoneBuffers
         return ZoneBuffers(self.obs_shape, self.obs_dtype, self.device, count=count,
-                           max_spacer_gib=self.placement_budget_gib, skip_gib=skip_gib)
+                           max_spacer_gib=getattr(self, "_budget_now", 0.0), skip_gib=skip_gib)
 
-    def _plain_obs_buffers(self, n: int, fallback: Optional[str] = None):
-        """Observation buffers as torch's allocator hands them out (small tensors, probe switched off, failed walk)."""
-        self.placement = {"spread": False, "method": "torch allocator"}
+    def _plain_obs_buffers(self, n: int, fallback: Optional[str] = None, policy: Optional[str] = None):
+        """Observation buffers as torch's allocator hands them out (small tensors, probe switched off, no walk on a shared
+        device, failed walk)."""
+        self.placement = {"spread": False, "method": "torch allocator", "candidates": 0, "budget_gib": 0.0,
+                          "policy": policy or ("no walk: observation tensor below 128 MiB or placement_probe off")}
+        self._zone_ptrs = set()
         if fallback is not None:
             self.placement["fallback"] = fallback
             torch.cuda.empty_cache()
@@ -533,12 +604,13 @@ class VecPogema:
             parked = ParkedBuffers.claim(self._shelf_key(), n)
             if parked is not None:  # buffers a closed environment of this shape left behind: no walk
                 bufs, info = parked
+                self._zone_ptrs = {t.data_ptr() for t in bufs}
                 self.placement = dict(info, method="pgx_buffers (two HBM zones per buffer; taken over from a closed environment)")
                 if self.batch >= 2048:
                     self.placement.update(self.tune_xcd_shares(bufs[0], bufs[-1] if n > 1 else None))
             else:
                 bufs = self._pick_obs_buffers(n)   # zone walk, candidates timed, the best n kept
-        return RecyclingOutputs(bufs, self.batch, self.num_agents)
+        return RecyclingOutputs(bufs, self.batch, self.num_agents, zone_ptrs=self._zone_ptrs)
 
     def _recycled(self, with_obs: bool = True):
         """reuse_buffers='recycle': an unreferenced output set, else (all sets still referenced by the caller / inside a
@@ -734,40 +806,9 @@ class VecPogema:
         if slots:
             obs_bytes = int(np.prod(self.obs_shape)) * (4 if self.obs_dtype == torch.float32 else 1)
             if self.placement_probe and slots <= 8 and obs_bytes >= self.PLACEMENT_MIN_BYTES:
-                entry = self._rollout_pools.get(slots)
-                if entry is None:
-                    # two buffers more than needed; the run of `slots` consecutive ones into which the observation
-                    # stream itself is fastest becomes the ring, the others are given back (see _pick_obs_buffers)
-                    retry = float(os.environ.get("PGX_POOL_RETRY", "1.10"))
-                    pool, times, start, skip = None, None, 0, 0.0
-                    for _ in range(3):  # as in _pick_obs_buffers: try further on while the ring misses the probe's promise
-                        try:
-                            cand = self._zone_pool(slots + 2, skip_gib=skip)
-                        except _lib.PgxError as e:  # failed walk (memory taken meanwhile): keep an earlier pool, if any
-                            if pool is None:
-                                self.placement = {"spread": False, "method": "torch allocator", "fallback": str(e)}
-                            break
-                        ct = [self._time_observe(t) for t in cand.tensors]
-                        cs = min(range(3), key=lambda s: (max(ct[s:s + slots]), s))
-                        if pool is None or max(ct[cs:cs + slots]) < max(times[start:start + slots]):
-                            pool, times, start = cand, ct, cs
-                        info = cand.info
-                        del cand
-                        if (not info["spread"] or info["final_us"] <= 0 or
-                                max(times[start:start + slots]) <= retry * info["final_us"] * obs_bytes / (2 * (384 << 20))):
-                            break
-                        skip = info["spacer_gib"] + 16.0
-                    if pool is not None:
-                        ring = pool.ring_view(start, slots)
-                        for i in range(slots + 2):
-                            if not start <= i < start + slots:
-                                pool.drop(i)
-                        entry = self._rollout_pools[slots] = (pool, ring)
-                        self.placement = dict(pool.info, method="pgx_buffers (two HBM zones per buffer)",
-                                              observe_us=[round(t, 1) for t in times[start:start + slots]],
-                                              observe_us_zone=[round(t, 1) for t in times])
-                        if "xcd_shares" not in self.placement and self._bufs is None:
-                            self.placement.update(self.tune_xcd_shares(ring[0], ring[1] if slots > 1 else None))
+                if slots not in self._rollout_pools:  # decided once per ring size (None = no ring: dense torch memory)
+                    self._rollout_pools[slots] = self._build_rollout_ring(slots, obs_bytes)
+                entry = self._rollout_pools[slots]
                 if entry is not None:
                     obs, slot_stride = entry[1], entry[0].stride_bytes
             if obs is None:
@@ -800,6 +841,53 @@ class VecPogema:
             if bad:
                 raise IndexError(f"{bad} action(s) of active agents were outside 0..{len(self.grid_config.MOVES) - 1}")
         return out
+
+    def _build_rollout_ring(self, slots: int, obs_bytes: int):
+        """(pool, ring view) of `slots` zone-spread observation slots for rollout(), or None (no walk under the policy of
+        `placement_budget_gib`, or a failed one).  Two buffers more than needed are built; the run of `slots` consecutive
+        ones into which the observation stream itself is fastest becomes the ring, the others are given back."""
+        from .buffers import walk_lock
+        budget, why, explicit = self._walk_policy()
+        if budget <= 0.0:
+            if self.placement is None:
+                self.placement = {"spread": False, "method": "torch allocator", "candidates": 0, "budget_gib": 0.0, "policy": why}
+            return None
+        with walk_lock(self.device_index, wait=explicit) as mine:
+            if not mine:
+                return None
+            self._budget_now = budget
+            retry = float(os.environ.get("PGX_POOL_RETRY", "1.10"))
+            pool, times, start, skip = None, None, 0, 0.0
+            for _ in range(3):  # as in _pick_obs_buffers: try further on while the ring misses the probe's promise
+                try:
+                    cand = self._zone_pool(slots + 2, skip_gib=skip)
+                except _lib.PgxError as e:  # failed walk (memory taken meanwhile): keep an earlier pool, if any
+                    if pool is None:
+                        self.placement = {"spread": False, "method": "torch allocator", "candidates": 0,
+                                          "budget_gib": round(budget, 1), "policy": why, "fallback": str(e)}
+                    break
+                ct = [self._time_observe(t) for t in cand.tensors]
+                cs = min(range(3), key=lambda s: (max(ct[s:s + slots]), s))
+                if pool is None or max(ct[cs:cs + slots]) < max(times[start:start + slots]):
+                    pool, times, start = cand, ct, cs
+                info = cand.info
+                del cand
+                if (not info["spread"] or info["final_us"] <= 0 or
+                        max(times[start:start + slots]) <= retry * info["final_us"] * obs_bytes / (2 * (384 << 20))):
+                    break
+                skip = info["spacer_gib"] + 16.0
+            if pool is None:
+                return None
+            ring = pool.ring_view(start, slots)
+            for i in range(slots + 2):
+                if not start <= i < start + slots:
+                    pool.drop(i)
+            self.placement = dict(pool.info, method="pgx_buffers (two HBM zones per buffer)", policy=why,
+                                  observe_us=[round(t, 1) for t in times[start:start + slots]],
+                                  observe_us_zone=[round(t, 1) for t in times])
+            if "xcd_shares" not in self.placement and self._bufs is None:
+                self.placement.update(self.tune_xcd_shares(ring[0], ring[1] if slots > 1 else None))
+            return pool, ring
 
     def set_targets(self, targets_xy, mask=None):
         """Overwrite current targets (int [batch, agents, 2], unpadded (row, col)) of the agents flagged in `mask`

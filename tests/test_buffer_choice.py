@@ -39,9 +39,7 @@ def test_recycling_outputs_on_cpu_tensors():
     import gc
     import torch
     from pogema_amd.buffers import RecyclingOutputs
-    if not RecyclingOutputs.available():
-        import pytest
-        pytest.skip("torch._C._storage_Use_Count missing in this torch build")
+    assert RecyclingOutputs.available(), "see test_storage_count_hook_still_means_what_the_recycler_assumes"
     B, A = 4, 3
     masters = [torch.zeros((B, A, 3, 5, 5)) for _ in range(2)]
     rec = RecyclingOutputs(masters, B, A)
@@ -68,3 +66,78 @@ def test_recycling_outputs_on_cpu_tensors():
     assert rec.free_sets() == 2
     d = rec.take()
     assert d[0].data_ptr() != first_ptr or len(rec) == 1  # least recently handed out first
+
+
+def test_storage_count_hook_still_means_what_the_recycler_assumes():
+    """reuse_buffers='recycle' reads a PRIVATE torch hook (torch._C._storage_Use_Count).  pogema_amd.buffers re-checks its
+    meaning on a tiny CPU tensor before using it and degrades to fresh tensors (with a warning) when it changed; this
+    test makes such a torch upgrade fail LOUDLY on the CPU instead of silently costing 20 % of the step time."""
+    import warnings
+    import pogema_amd.buffers as B
+    B._HOOK = B._UNSET
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        hook = B.storage_count_hook()
+    assert hook is not None, f"torch {torch.__version__}: the storage use-count hook is gone or changed its meaning"
+    t = torch.zeros(4)
+    c = t.untyped_storage()._cdata
+    n = hook(c)
+    u = t.view(2, 2)
+    assert hook(c) == n + 1
+    del u
+    assert hook(c) == n
+
+
+def test_a_changed_hook_degrades_with_a_warning(monkeypatch):
+    import pogema_amd.buffers as B
+    monkeypatch.setattr(B, "_HOOK", B._UNSET)
+    monkeypatch.setattr(torch._C, "_storage_Use_Count", lambda cdata: 1)  # "changed its meaning"
+    with pytest.warns(RuntimeWarning, match="no longer counts"):
+        assert B.storage_count_hook() is None
+    assert not B.RecyclingOutputs.available()
+    monkeypatch.setattr(B, "_HOOK", B._UNSET)
+    monkeypatch.delattr(torch._C, "_storage_Use_Count")
+    with pytest.warns(RuntimeWarning, match="missing"):
+        assert B.storage_count_hook() is None
+    monkeypatch.undo()
+    B._HOOK = B._UNSET
+    assert B.storage_count_hook() is not None
+
+
+def test_parked_buffers_keep_whole_sets_only(monkeypatch):
+    """the shelf of closed environments' buffers holds only claimable sets, evicts whole sets, refuses sets
+    above the limit and partial returns, and clear() empties it."""
+    from pogema_amd.buffers import ParkedBuffers as P
+    P.clear()
+    monkeypatch.setenv("PGX_POOL_CACHE_MB", "3")
+    mb = lambda n=1: torch.zeros(n << 20, dtype=torch.uint8)  # noqa: E731
+    assert P.park("a", [mb(), mb()], {"spread": True}, 3) is False and P.bytes_parked() == 0   # fewer than a set: nothing kept
+    assert P.park("a", [mb(), mb(), mb(), mb()], {"spread": True}, 3) is True                   # surplus buffer released
+    assert P.bytes_parked() == 3 << 20
+    assert P.claim("a", 2) is None                       # a set of another size is not claimable as such
+    assert P.park("b", [mb(2), mb(2)], {}, 2) is False   # one set alone above the limit: not parked, "a" untouched
+    assert P.bytes_parked() == 3 << 20
+    assert P.park("c", [mb()], {"spread": False}, 1) is True   # limit exceeded: the oldest WHOLE set goes
+    assert P.bytes_parked() == 1 << 20 and P.claim("a", 3) is None
+    got = P.claim("c", 1)
+    assert got is not None and len(got[0]) == 1 and got[1] == {"spread": False} and P.bytes_parked() == 0
+    monkeypatch.setenv("PGX_POOL_CACHE_MB", "0")
+    assert P.park("d", [mb()], {}, 1) is False           # shelf switched off
+    monkeypatch.setenv("PGX_POOL_CACHE_MB", "8")
+    assert P.park("d", [mb()], {}, 1) and P.park("d", [mb()], {}, 1) and P.bytes_parked() == 2 << 20
+    P.clear()
+    assert P.bytes_parked() == 0 and P.claim("d", 1) is None
+
+
+def test_walk_lock_admits_one_walker_per_device():
+    """The default policy skips the zone walk when another process (here: another open file description) is walking the
+    same device; an explicit budget waits instead (not exercised: it would block)."""
+    from pogema_amd.buffers import walk_lock
+    with walk_lock(0) as first:
+        assert first is True
+        with walk_lock(0) as second:
+            assert second is False, "a second concurrent walker of the same device must be turned away"
+        with walk_lock(1) as other_device:
+            assert other_device is True
+    with walk_lock(0) as again:
+        assert again is True, "the lock is released when the walk ends"

@@ -59,7 +59,7 @@ def test_engine_parity_on_zone_buffers():
     B = 1024  # 1024 x 32 x 1452 B = 47.6 MB per buffer: below the pool threshold -> force it
     envs = []
     for reuse in (False, True):
-        env = VecPogema(gc, batch=B, auto_reset=True, reuse_buffers=reuse)
+        env = VecPogema(gc, batch=B, auto_reset=True, reuse_buffers=reuse, placement_budget_gib=8.0)  # explicit: walk
         env.PLACEMENT_MIN_BYTES = 1 << 20
         env.reset(seed=3)
         envs.append(env)
@@ -79,7 +79,7 @@ def test_failed_walk_falls_back_to_plain_buffers(monkeypatch):
     import torch
     from pogema_amd import GridConfig, VecPogema, _lib
     gc = GridConfig(size=16, num_agents=8, obs_radius=3, density=0.2, seed=1)
-    env = VecPogema(gc, batch=64, auto_reset=True, reuse_buffers=True)
+    env = VecPogema(gc, batch=64, auto_reset=True, reuse_buffers=True, placement_budget_gib=4.0)
     env.PLACEMENT_MIN_BYTES = 1  # force the pool path for this small tensor
     calls = []
 
@@ -168,7 +168,7 @@ def test_recycle_mode_never_aliases_and_takes_sets_back():
     cfg = GridConfig(size=32, num_agents=32, obs_radius=5, density=0.3, seed=3, collision_system="soft")
     B = 512
     ref = VecPogema(cfg, batch=B, auto_reset=True, reuse_buffers=False)
-    env = VecPogema(cfg, batch=B, auto_reset=True)  # default
+    env = VecPogema(cfg, batch=B, auto_reset=True, placement_budget_gib=8.0)  # default mode; the walk asked for explicitly
     assert env.recycle and not env.reuse_buffers
     env.PLACEMENT_MIN_BYTES = 1 << 20  # 23.8 MB per tensor: force the pool path
     ref.reset(seed=3)
@@ -236,10 +236,64 @@ def test_recycle_mode_small_tensors_and_missing_hook(monkeypatch):
     env.close()
 
 
-@pytest.mark.parametrize("budget", [0, 1.0, "all"])
+def test_default_policy_walks_only_on_a_device_that_is_ours(monkeypatch):
+    """placement_budget_gib=None (the default) must not hold half of a SHARED device.  The walk runs only when
+    >= 90 % of the device's memory is free and nobody else is walking it; otherwise there is no walk, no timing
+    allocations, no cache flush -- plain torch buffers, recycled all the same -- and `placement["policy"]` says why."""
+    import torch
+    from pogema_amd import GridConfig, VecPogema, buffers
+    cfg = GridConfig(size=32, num_agents=32, obs_radius=5, density=0.3, seed=5)
+    B = 3000  # 139 MB per observation tensor: above the walk threshold
+    acts = torch.randint(0, 5, (B, 32), device="cuda", dtype=torch.int8)
+    real = torch.cuda.mem_get_info
+    total = real(0)[1]
+    walks = []
+    orig_pool = VecPogema._zone_pool
+
+    def counting_pool(self, count, skip_gib=0.0):
+        walks.append(self._budget_now)
+        return orig_pool(self, count, skip_gib)
+
+    monkeypatch.setattr(VecPogema, "_zone_pool", counting_pool)
+    flushes = []
+    monkeypatch.setattr(torch.cuda, "empty_cache", lambda: flushes.append(1))
+    # (1) a loaded / shared device: 60 % free
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda *a: (int(0.6 * total), total))
+    env = VecPogema(cfg, batch=B, auto_reset=True)
+    env.reset(seed=5)
+    obs = env.step(acts)[0]
+    assert not walks and not flushes and env.placement["method"] == "torch allocator"
+    assert "shared or already loaded" in env.placement["policy"] and env.placement["budget_gib"] == 0.0
+    assert env._recycler and len(env._recycler) == 2 and obs.data_ptr() in set(env._recycler.obs_pointers())
+    env.close()
+    # (2) the same, but the caller asks: explicit budgets walk wherever they are
+    env = VecPogema(cfg, batch=B, auto_reset=True, placement_budget_gib=2.0)
+    env.reset(seed=5)
+    assert walks and walks[0] == 2.0 and env.placement["policy"].startswith("explicit") and env.placement["budget_gib"] == 2.0
+    env.close(release=True)
+    assert buffers.ParkedBuffers.bytes_parked() == 0
+    # (3) an empty device, but another process holds the walk lock: it is not ours alone -> no walk, and no waiting
+    del walks[:]
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda *a: (int(0.97 * total), total))
+    with buffers.walk_lock(0) as held:
+        assert held
+        env = VecPogema(cfg, batch=B, auto_reset=True)
+        env.reset(seed=5)
+        assert not walks and "another process is walking" in env.placement["policy"]
+        env.close()
+    # (4) an empty device and nobody else: the walk runs with half of the free memory
+    env = VecPogema(cfg, batch=B, auto_reset=True)
+    env.reset(seed=5)
+    assert walks and abs(walks[0] - 0.5 * 0.97 * total / 2 ** 30) < 1.0 and env.placement["policy"].startswith("auto")
+    assert env.placement["method"].startswith("pgx_buffers")
+    env.close(release=True)
+    monkeypatch.setattr(torch.cuda, "mem_get_info", real)
+
+
+@pytest.mark.parametrize("budget", [0, 1.0, "half", "all"])
 def test_placement_budget_parameter(budget):
-    """VecPogema(placement_budget_gib=...): 0 = no walk (buffers still come from the pool, unspread), a number = GiB the
-    walk may hold, "all" = everything but the engine's reserve; results are the same tensors either way."""
+    """VecPogema(placement_budget_gib=...): 0 = never walk (plain torch buffers), a number = GiB the walk may hold, "half" =
+    half of the free memory, "all" = everything but the engine's reserve; results are the same tensors either way."""
     import torch
     from pogema_amd import GridConfig, VecPogema
     cfg = GridConfig(size=32, num_agents=32, obs_radius=5, density=0.3, seed=5, collision_system="priority")
@@ -250,11 +304,15 @@ def test_placement_budget_parameter(budget):
     r, _ = ref.reset(seed=5)
     assert torch.equal(o, r)
     pl = env.placement
-    assert pl["method"].startswith("pgx_buffers")
+    assert pl["policy"].startswith("explicit")
     if budget == 0:
-        assert pl["budget_gib"] == 0 and pl["candidates"] == 0 and not pl["spread"]
-    elif budget == 1.0:
+        assert pl["method"] == "torch allocator" and pl["budget_gib"] == 0 and pl["candidates"] == 0 and not pl["spread"]
+    else:
+        assert pl["method"].startswith("pgx_buffers")
+    if budget == 1.0:
         assert pl["budget_gib"] == 1.0 and pl["spacer_gib"] <= 1.0
+    with pytest.raises(ValueError):
+        VecPogema(cfg, batch=4, placement_budget_gib="lots")
     acts = torch.randint(0, 5, (3, B, 32), device="cuda", dtype=torch.int8)
     for t in range(3):
         a, b = env.step(acts[t]), ref.step(acts[t])
@@ -263,9 +321,10 @@ def test_placement_budget_parameter(budget):
 
 
 def test_closed_environments_leave_their_buffers_to_the_next_one(monkeypatch):
-    """buffers.ParkedBuffers: close() parks the zone-spread observation buffers nobody references any more; the next
-    environment with the same observation tensor takes them over without a walk (and without new address space); a
-    buffer the caller still holds is NOT parked; PGX_POOL_CACHE_MB=0 switches the shelf off."""
+    """buffers.ParkedBuffers: close() parks the zone-spread observation buffers nobody references any more -- as a WHOLE
+    set or not at all --; the next environment with the same observation tensor takes them over without a
+    walk (and without new address space); a set the caller still holds a buffer of is NOT parked (the shelf never holds
+    an unclaimable remainder); PGX_POOL_CACHE_MB=0 switches the shelf off; close(release=True) empties it."""
     import gc as pygc
     import torch
     from pogema_amd import GridConfig, VecPogema, _lib
@@ -279,17 +338,21 @@ def test_closed_environments_leave_their_buffers_to_the_next_one(monkeypatch):
     want = [ref.step(acts[t])[0] for t in range(4)]
     key = (0, (B, 32, 3, 11, 11), torch.float32)
 
-    a = VecPogema(cfg, batch=B, auto_reset=True)
+    a = VecPogema(cfg, batch=B, auto_reset=True, placement_budget_gib="half")
     a.reset(seed=3)
     assert a.placement["method"] == "pgx_buffers (two HBM zones per buffer)" and len(a._recycler) == 2
     ptrs_a = set(a._recycler.obs_pointers())
     assert torch.equal(a.step(acts[0])[0], want[0])
     a.close()
     pygc.collect()
-    assert len(ParkedBuffers._shelf[key]) == 2
+    if len(a._zone_ptrs) == 2:  # (the candidate timing may prefer one of torch's own buffers: then no whole zone set exists)
+        assert len(ParkedBuffers._shelf[key]) == 1 and len(ParkedBuffers._shelf[key][0][0]) == 2
+        assert ParkedBuffers.bytes_parked() == 2 * B * 32 * 3 * 121 * 4
+    else:
+        pytest.skip("the pool's buffers lost the candidate timing on this box: nothing to park")
 
     va = int(lib.pgx_buffers_va_reserved())
-    b = VecPogema(cfg, batch=B, auto_reset=True)
+    b = VecPogema(cfg, batch=B, auto_reset=True, placement_budget_gib="half")
     b.reset(seed=3)
     assert "taken over from a closed environment" in b.placement["method"] and key not in ParkedBuffers._shelf
     assert set(b._recycler.obs_pointers()) == ptrs_a and int(lib.pgx_buffers_va_reserved()) == va
@@ -297,13 +360,24 @@ def test_closed_environments_leave_their_buffers_to_the_next_one(monkeypatch):
         assert torch.equal(b.step(acts[t])[0], want[t])
     held = b.step(acts[0])[0]  # the caller keeps this one: its buffer must not be parked
     b.close()
-    assert len(ParkedBuffers._shelf[key]) == 1 and held.data_ptr() not in {t.data_ptr() for t, _ in ParkedBuffers._shelf[key]}
+    assert key not in ParkedBuffers._shelf and ParkedBuffers.bytes_parked() == 0  # one of two: not a set -> nothing is kept
 
-    c = VecPogema(cfg, batch=B, auto_reset=True)  # needs two, one is parked: its own walk
+    c = VecPogema(cfg, batch=B, auto_reset=True, placement_budget_gib="half")  # nothing parked: its own walk
     c.reset(seed=3)
-    assert c.placement["method"] == "pgx_buffers (two HBM zones per buffer)" and len(ParkedBuffers._shelf[key]) == 1
+    assert c.placement["method"] == "pgx_buffers (two HBM zones per buffer)"
     assert held.data_ptr() not in set(c._recycler.obs_pointers())
     monkeypatch.setenv("PGX_POOL_CACHE_MB", "0")
     c.close()
-    assert len(ParkedBuffers._shelf[key]) == 1  # switched off: nothing added
+    assert ParkedBuffers.bytes_parked() == 0  # switched off: nothing added
+    monkeypatch.delenv("PGX_POOL_CACHE_MB")
+    d = VecPogema(cfg, batch=B, auto_reset=True, placement_budget_gib="half")
+    d.reset(seed=3)
+    whole = len(d._zone_ptrs) == 2
+    d.close()
+    assert (ParkedBuffers.bytes_parked() > 0) == whole
+    e = VecPogema(cfg, batch=4, auto_reset=True)
+    e.close(release=True)  # ... gives back what earlier environments left behind, too
+    assert ParkedBuffers.bytes_parked() == 0
+    from pogema_amd import release_cached_buffers
+    release_cached_buffers()
     ref.close()

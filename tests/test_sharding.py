@@ -49,6 +49,7 @@ def _worker(rank, world, port, tmpdir):
         got_xy = gather_to_host(torch.from_numpy(state["agents_xy"]), GB)
         got_tgt = gather_to_host(torch.from_numpy(state["targets_xy"]), GB)
         got_map = gather_to_host(torch.from_numpy(obstacles), GB)
+        got_flags = gather_to_host(torch.from_numpy(np.ascontiguousarray(act)), GB)  # bool: gloo has none, travels as bytes
         if rank == 0:
             # the unsharded run
             o1, a1, t1 = generate_instances(GB, H, W, A, 0.2, seed)
@@ -56,7 +57,8 @@ def _worker(rank, world, port, tmpdir):
             ref.reset(o1, a1, t1)
             full_actions = random_actions(T, GB, A, 5)
             for t in range(T):
-                robs, *_ = ref.step(full_actions[t])
+                robs, _, _, _, ract = ref.step(full_actions[t])
+            assert got_flags.dtype == torch.bool and np.array_equal(got_flags.numpy(), ract)
             rstate = ref.get_state()
             assert np.array_equal(got_map.numpy(), o1)
             assert np.array_equal(got_xy.numpy(), rstate["agents_xy"])

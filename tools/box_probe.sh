@@ -1,14 +1,41 @@
 #!/bin/bash
-# Diagnostic: what kind of box is this?  Clocks / power / temperature sampled WHILE the step kernel runs, next to the
-# kernel's and the pure store stream's speed.
-rocm-smi --showuniqueid 2>/dev/null | grep -i "unique id"
-( for i in $(seq 1 60); do rocm-smi --showclocks --showpower --showtemp 2>/dev/null | grep -i "sclk\|mclk\|fclk\|Power (W)\|junction\|(Sensor memory)" | sed 's/GPU\[0\]\s*: //' | tr -s ' \t' ' ' | tr '\n' ';'; echo; sleep 0.25; done ) > /tmp/probe_samples.txt &
-SP=$!
-python bench.py --steps 40000 --no-cpu-baseline > /tmp/probe_bench.json 2>/dev/null
-kill $SP 2>/dev/null
-sort -t'(' -k4 /tmp/probe_samples.txt | awk '/sclk/' | sort -u | tail -4
-python - <<'PY'
-import json
-d=json.loads(open("/tmp/probe_bench.json").readline()); print("kernel_us %.1f" % (d["roofline"]["kernel_ms"]*1e3))
+# What kind of box is this lease?  (VERDICT r3 #3a)  Run BEFORE a benchmark on the same gpurun call and keep the output
+# next to the bench line: partition modes (compute SPX/CPX..., memory NPS1/NPS4...), VRAM vendor / size, the KFD memory
+# banks, firmware -- so that "zone" and "no-zone" boxes can be told apart by something other than timing.
+#   tools/box_probe.sh [out.json]        default: gpurun_out/box_fingerprint.json
+# bench.py embeds the sysfs part of this in every JSON line (`box`); this script adds what needs the smi tools.
+cd "$(dirname "$0")/.." || exit 1
+OUT=${1:-gpurun_out/box_fingerprint.json}
+mkdir -p "$(dirname "$OUT")"
+TXT="${OUT%.json}.txt"
+{
+  echo "== date: $(date -u +%FT%TZ)  host: $(hostname)  kernel: $(uname -r)"
+  echo "== rocm-smi partitions"
+  timeout 60 rocm-smi --showmemorypartition --showcomputepartition 2>&1 | grep -v "^=\|^$" | head -20
+  echo "== rocm-smi ids / vram / firmware"
+  timeout 60 rocm-smi --showuniqueid --showmeminfo vram --showvbios --showbus 2>&1 | grep -v "^=\|^$" | head -30
+  echo "== rocm-smi clocks"
+  timeout 60 rocm-smi --showclocks 2>&1 | grep -i "sclk\|mclk\|fclk\|socclk" | head -12
+  if command -v amd-smi >/dev/null 2>&1; then
+    echo "== amd-smi static (partition, vram, board)"
+    timeout 90 amd-smi static --partition --vram --board --asic 2>&1 | head -80
+  fi
+  echo "== lscpu"
+  lscpu 2>/dev/null | grep -i "model name\|^CPU(s)\|socket\|numa node(s)" | head -6
+  echo "== /proc/meminfo"
+  grep -i "memtotal\|hugepages_total" /proc/meminfo
+} > "$TXT" 2>&1
+python3 - "$OUT" <<'PY'
+import json, sys
+sys.path.insert(0, ".")
+import bench
+fp = bench.box_fingerprint()
+json.dump(fp, open(sys.argv[1], "w"), indent=1)
+cards = fp["drm_cards"]
+print("box:", fp["hostname"], "| GPUs:", len(cards), "|",
+      "; ".join(f"{c['card']} {c['compute_partition']}/{c['memory_partition']} vram {c['vram_vendor']} {c['vram_total']} uid {c['unique_id']}" for c in cards))
+for n in fp["kfd_gpu_nodes"]:
+    print(" kfd node", n["node"], {k: n[k] for k in ("num_xcc", "simd_count", "max_engine_clk_fcompute", "local_mem_size")},
+          "banks:", [(b["heap_type"], b["size_in_bytes"], b["width"], b["mem_clk_max"]) for b in n["mem_banks"]])
 PY
-tools/store_sweep | head -1
+echo "-> $OUT, $TXT"

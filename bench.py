@@ -184,6 +184,18 @@ def box_fingerprint():
             bp = _props(os.path.join(bank, "properties"))
             banks.append({k: bp.get(k) for k in ("heap_type", "size_in_bytes", "flags", "width", "mem_clk_max")})
         nodes.append({"node": int(os.path.basename(node)), **{k: pr.get(k) for k in keep}, "mem_banks": banks})
+    # the cards of the HOST are all listed in sysfs; the process sees the KFD nodes its cgroup admits: match by unique id
+    mine = {int(n["unique_id"]) for n in nodes if isinstance(n.get("unique_id"), int)}
+    for c in cards:
+        try:
+            c["visible_to_this_process"] = int(c["unique_id"], 16) in mine
+        except (TypeError, ValueError):
+            c["visible_to_this_process"] = None
+    hidden = [c for c in cards if c["visible_to_this_process"] is False]
+    if hidden and len(hidden) < len(cards):  # keep the line short: full details of this process's GPUs only
+        cards = [c for c in cards if c["visible_to_this_process"] is not False]
+        cards.append({"other_cards_on_host": len(hidden), "their_partitions": sorted({f"{c['compute_partition']}/{c['memory_partition']}" for c in hidden}),
+                      "their_vram_vendors": sorted({str(c["vram_vendor"]) for c in hidden})})
     return {"drm_cards": cards, "kfd_gpu_nodes": nodes, "kernel": _read("/proc/sys/kernel/osrelease"),
             "amdgpu_version": _read("/sys/module/amdgpu/version"), "hostname": socket.gethostname()}
 

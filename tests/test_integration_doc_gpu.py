@@ -92,7 +92,7 @@ def test_documented_stub_lands_on_the_fast_tier():
     actions = [torch.randint(0, 5, (B, A), generator=gen, device="cuda") for _ in range(8)]  # int64, as the stub passes them
 
     stub = ns["AmdVecPogema"](gc, B, auto_reset=1)
-    first = stub.reset_from_grids([_FakeGrid(obstacles[b], agents[b], targets[b]) for b in range(B)])
+    first = stub.reset_from_grids([_FakeGrid(obstacles[b], agents[b], targets[b]) for b in range(B)]).clone()  # (a rotating buffer)
     info = _lib.PgxBuffersInfo()
     ns["lib"].pgx_buffers_get_info(stub.pool, C.byref(info))
     stub_us = _us_per_step(stub.step, actions)
@@ -108,7 +108,7 @@ def test_documented_stub_lands_on_the_fast_tier():
     assert torch.equal(o_stub, o_ours), "the documented stub and VecPogema disagree after 801 steps"
     spread_ours = bool(env.placement.get("spread"))
     env.close(release=True)
-    del o_ours, obs0
+    del o_ours, obs0, first
 
     plain = VecPogema(gc, batch=B, auto_reset=True, reuse_buffers=False)
     plain.reset_from_state(obstacles, agents, targets, validate=False)

@@ -53,7 +53,8 @@ def test_configs3_full_batch_as_eight_shards():
                                      targets[start:start + count], validate=False)
         assert torch.equal(first, obs[start:start + count])
         shards.append(env)
-    assert shards[0].geometry() == shards[-1].geometry(), "every rank runs the same launch shape"
+    shape = lambda e: {k: v for k, v in e.geometry().items() if k != "grid"}  # noqa: E731  (grid: per-engine XCD share tuning)
+    assert shape(shards[0]) == shape(shards[-1]), "every rank runs the same launch shape"
     del obs, ref_obs, first
     rng = np.random.default_rng(5)
     threads = min(32, len(os.sched_getaffinity(0)))

@@ -32,8 +32,8 @@ import bench
 fp = bench.box_fingerprint()
 json.dump(fp, open(sys.argv[1], "w"), indent=1)
 cards = fp["drm_cards"]
-print("box:", fp["hostname"], "| GPUs:", len(cards), "|",
-      "; ".join(f"{c['card']} {c['compute_partition']}/{c['memory_partition']} vram {c['vram_vendor']} {c['vram_total']} uid {c['unique_id']}" for c in cards))
+print("box:", fp["hostname"], "| GPUs visible:", sum(1 for c in cards if c.get("visible_to_this_process")), "|",
+      "; ".join(f"{c['card']} {c['compute_partition']}/{c['memory_partition']} vram {c['vram_vendor']} {c['vram_total']} uid {c['unique_id']}" if "card" in c else str(c) for c in cards))
 for n in fp["kfd_gpu_nodes"]:
     print(" kfd node", n["node"], {k: n[k] for k in ("num_xcc", "simd_count", "max_engine_clk_fcompute", "local_mem_size")},
           "banks:", [(b["heap_type"], b["size_in_bytes"], b["width"], b["mem_clk_max"]) for b in n["mem_banks"]])

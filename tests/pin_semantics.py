@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Which position of every semantics switch do reference fixtures demand?  (test infrastructure.)
+
+    python tests/pin_semantics.py DIR          DIR holds reference_*.npz (+ reference_probes.json) of tools/gen_golden.py
+
+Brute force: every combination of the step-semantics switches (soft_vertex x soft_occupancy x coop_reward x bad_action =
+2^4) is run through the literal Python oracle over every fixture -- positions, flags, rewards, observations, the occupancy
+array and the final metrics, exactly the comparison of tests/test_golden_reference.py -- and the combinations under which
+ALL fixtures pass are reported, per switch: `determined` when every passing combination agrees on it, `free` when the
+fixtures cannot tell (e.g. bad_action: rollouts only contain valid actions -- reference_probes.json decides that one).
+Prints one JSON object; exit code 0 iff at least one combination passes.  The product's defaults
+(pogema_amd.Semantics()) are flagged when they are not among the passing combinations: that is the flip to make.
+"""
+import glob
+import itertools
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main(argv):
+    if len(argv) != 2:
+        sys.exit(__doc__)
+    os.environ["PGX_GOLDEN_DIR"] = os.path.abspath(argv[1])
+    import test_golden_reference as tgr
+    from pogema_amd.semantics import BAD_ACTION, COOP_REWARD, SOFT_OCCUPANCY, SOFT_VERTEX, Semantics
+    from util import oracle_rollout
+    fixtures = sorted(glob.glob(os.path.join(os.environ["PGX_GOLDEN_DIR"], "reference_*.npz")))
+    if not fixtures:
+        sys.exit(f"no reference_*.npz under {argv[1]}")
+    switches = {"soft_vertex": SOFT_VERTEX, "soft_occupancy": SOFT_OCCUPANCY, "coop_reward": COOP_REWARD, "bad_action": BAD_ACTION}
+    names = list(switches)
+    passing, first_failure = [], {}
+    for combo in itertools.product(*switches.values()):
+        sem = Semantics(**dict(zip(names, combo)))
+
+        def run(*a, **kw):
+            return oracle_rollout(*a, semantics=sem, **kw)
+
+        ok = True
+        for path in fixtures:
+            try:
+                tgr.compare_with_fixture(run, path)
+            except (AssertionError, IndexError) as exc:
+                ok = False
+                msg = next((ln.strip() for ln in str(exc).splitlines() if ln.strip()), type(exc).__name__)
+                first_failure[",".join(combo)] = f"{os.path.basename(path)}: {msg[:160]}"
+                break
+        if ok:
+            passing.append(dict(zip(names, combo)))
+    verdict = {}
+    for n in names:
+        seen = sorted({c[n] for c in passing})
+        verdict[n] = {"determined": seen[0]} if len(seen) == 1 else {"free": seen} if seen else {"no combination passes": True}
+    probes = {}
+    probe_file = os.path.join(os.environ["PGX_GOLDEN_DIR"], "reference_probes.json")
+    if os.path.exists(probe_file):
+        probes = json.load(open(probe_file))
+        ba = str(probes.get("bad_action", ""))
+        if "free" in verdict.get("bad_action", {}) and ba:
+            verdict["bad_action"] = {"determined_by_probe": "flag" if ba.startswith("raises IndexError") else "noop" if ba == "noop" else ba}
+    default = {n: getattr(Semantics(), n) for n in names}
+    report = {"fixtures": len(fixtures), "combinations_tried": 2 ** len(names), "passing": passing, "per_switch": verdict,
+              "product_default": default, "product_default_passes": default in passing,
+              "probes": probes, "first_failure_of_failing_combinations": first_failure}
+    print(json.dumps(report, indent=1))
+    return 0 if passing else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv))

@@ -43,6 +43,10 @@ class _Grid:
         g = self._env._oracle.grid
         return [list(p) for p in (g.unpadded_xy(g.finishes_xy) if ignore_borders else g.finishes_xy)]
 
+    @property
+    def positions(self):  # the padded occupancy array, `Grid.positions` upstream
+        return self._env._oracle.grid.positions
+
 
 class _Env:
     def __init__(self, grid_config):
@@ -61,8 +65,11 @@ class _Env:
             # upstream's generator as recalled, written with numpy itself (the checker of pgx_np_generate)
             obstacles, agents, targets = _G.generate_instance_numpy(seed or 0, h, w, gc.num_agents, gc.density,
                                                                     given_map=gc.map)
+        # PGX_STANDIN_SEMANTICS="soft_vertex_rule=all_stay,soft_occupancy=exact,...": a stand-in whose switches are NOT the
+        # defaults -- tests/test_golden_pipeline.py checks that tools/pin_reference.sh finds them from the fixtures alone
+        sem = dict(item.split("=", 1) for item in os.environ.get("PGX_STANDIN_SEMANTICS", "").split(",") if "=" in item)
         self._oracle = _Oracle(obstacles, agents, targets, obs_radius=gc.obs_radius, collision_system=gc.collision_system,
-                               on_target=gc.on_target, max_episode_steps=gc.max_episode_steps, seed=gc.seed or 0)
+                               on_target=gc.on_target, max_episode_steps=gc.max_episode_steps, seed=gc.seed or 0, **sem)
         return self._oracle._obs(), [{"is_active": True} for _ in range(gc.num_agents)]
 
     def step(self, actions):

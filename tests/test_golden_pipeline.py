@@ -113,3 +113,40 @@ def test_device_generator_pin_on_the_loaded_fixtures(fixtures):
 def test_engine_passes_the_loaded_fixtures(fixtures):
     for path in fixtures:
         tgr.compare_with_fixture(engine_rollout, path)
+
+
+def _pin(out_dir, standin_semantics=""):
+    env = dict(os.environ, PYTHONPATH=STANDIN + os.pathsep + os.environ.get("PYTHONPATH", ""),
+               PGX_STANDIN_SEMANTICS=standin_semantics)
+    env.pop("PGX_SEMANTICS", None)
+    p = subprocess.run(["bash", os.path.join(ROOT, "tools", "pin_reference.sh"), "--out", str(out_dir), "--geoms", "3,0",
+                        "--limit", "36"], capture_output=True, text=True, env=env, timeout=1500)
+    import json
+    return p, json.load(open(os.path.join(str(out_dir), "pin_report.json")))
+
+
+def test_pin_reference_script_finds_the_standins_switches(tmp_path):
+    """tools/pin_reference.sh end to end: generate -> brute-force the 2^4 switch positions over the fixtures
+    -> default-semantics tests.  The stand-in's switches are the product defaults, so everything passes and every switch a
+    rollout can show is DETERMINED by the fixtures (the collision-dense geometry exercises the soft-collision ones), the
+    out-of-range-action one by the probe file."""
+    p, rep = _pin(tmp_path / "default")
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert rep["fixtures"] == 36 and rep["combinations_tried"] == 16 and rep["product_default_passes"] is True
+    sw = rep["per_switch"]
+    assert sw["soft_vertex"] == {"determined": "lowest_index"} and sw["soft_occupancy"] == {"determined": "index_order"}
+    assert sw["coop_reward"] == {"determined": "all_solved"} and sw["bad_action"] == {"determined_by_probe": "noop"}
+    assert rep["probes"]["standin"] is True and rep["probes"]["grid_config_defaults"]["collision_system"] == "priority"
+    z = np.load(sorted(glob.glob(os.path.join(str(tmp_path / "default"), "reference_12x40_soft_*.npz")))[0], allow_pickle=False)
+    assert z["positions"].shape[0] == z["actions"].shape[0] and z["positions0"].ndim == 2 and "metrics_names" in z.files
+
+
+def test_pin_reference_script_names_the_flip_for_a_different_reference(tmp_path):
+    """A 'reference' whose low-confidence details are all the OTHER way round (stand-in with non-default switches): the
+    default-semantics tests fail, and the report names exactly the switches to flip -- from the fixtures alone."""
+    p, rep = _pin(tmp_path / "flipped", "soft_vertex_rule=all_stay,soft_occupancy=exact,coop_reward=per_agent,bad_action=flag")
+    assert p.returncode != 0 and rep["product_default_passes"] is False
+    sw = rep["per_switch"]
+    assert sw["soft_vertex"] == {"determined": "all_stay"} and sw["soft_occupancy"] == {"determined": "exact"}
+    assert sw["coop_reward"] == {"determined": "per_agent"} and sw["bad_action"] == {"determined_by_probe": "flag"}
+    assert {"soft_vertex": "all_stay", "soft_occupancy": "exact", "coop_reward": "per_agent", "bad_action": "noop"} in rep["passing"]

@@ -22,8 +22,11 @@ import pytest
 
 from util import assert_rollouts_equal, engine_rollout, oracle_rollout
 
-FIXTURES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "reference_*.npz")))
+# PGX_GOLDEN_DIR: fixtures somewhere else than tests/golden (tools/pin_reference.sh --out DIR; the stand-in rehearsal)
+GOLDEN_DIR = os.environ.get("PGX_GOLDEN_DIR") or os.path.join(os.path.dirname(__file__), "golden")
+FIXTURES = sorted(glob.glob(os.path.join(GOLDEN_DIR, "reference_*.npz")))
 KEYS = ("obs0", "obs", "rewards", "terminated", "truncated", "is_active", "agents_xy", "targets_xy")
+METRIC_NAMES = ("ISR", "CSR", "ep_length", "SoC", "makespan", "avg_throughput")  # column order of the engine's metrics
 
 
 def _load(path):
@@ -34,6 +37,12 @@ def _load(path):
         ref[k] = ref[k][:, None]  # batch axis: one environment per fixture
     ref["obs0"] = ref["obs0"][None]
     ref["elapsed"] = np.arange(1, T + 1, dtype=np.int32)[:, None]
+    if "positions" in z.files:  # round 4 fixtures: the occupancy array itself (`grid.positions`, padded)
+        ref["occupancy0"] = z["positions0"][None].astype(np.uint8)
+        ref["occupancy"] = z["positions"][:, None].astype(np.uint8)
+    if "metrics_names" in z.files:  # infos[0]['metrics'] of the step that ended the episode: only the names both sides know
+        row = dict(zip(str(z["metrics_names"]).split("|"), np.asarray(z["metrics_values"], dtype=np.float64)))
+        ref["metrics_final"] = (int(z["metrics_step"]), row)
     kw = dict(obs_radius=int(z["obs_radius"]), collision_system=str(z["collision_system"]), on_target=str(z["on_target"]),
               max_episode_steps=int(z["max_episode_steps"]), auto_reset=False)
     return z["obstacles"][None], z["agents_xy0"][None], z["targets_xy0"][None], z["actions"][:, None, :], ref, kw
@@ -43,7 +52,16 @@ def compare_with_fixture(run, path):
     """`run` = oracle_rollout or engine_rollout; raises AssertionError on the first difference."""
     obstacles, agents, targets, actions, ref, kw = _load(path)
     lifelong = kw["on_target"] == "restart"
-    got = run(obstacles, agents, targets, actions, inject_targets=ref["targets_xy"] if lifelong else None, **kw)
+    extra = {"with_occupancy": True} if ("occupancy" in ref and run is engine_rollout) else {}
+    got = run(obstacles, agents, targets, actions, inject_targets=ref["targets_xy"] if lifelong else None, **kw, **extra)
+    final = ref.pop("metrics_final", None)
+    if final is not None:  # docs/SPEC.md Q9: the metric wrappers' formulas, for every name the reference reports
+        step, row = final
+        assert got["episode_done"][step, 0], f"{os.path.basename(path)}: the reference ended its episode in step {step}"
+        for name, want in row.items():
+            if name in METRIC_NAMES:
+                have = float(got["metrics"][step, 0, METRIC_NAMES.index(name)])
+                assert abs(have - want) <= 1e-6 * max(1.0, abs(want)), f"{os.path.basename(path)}: metric {name} = {have}, reference {want}"
     got = {k: v for k, v in got.items() if k in ref}
     if lifelong:
         drew = ref["rewards"] > 0  # [T, 1, A]: reached its goal in this step -> the reference drew a new target

@@ -68,7 +68,9 @@ def oracle_rollout(obstacles, agents, targets, actions, *, obs_radius, collision
         "is_active": np.zeros((T, B, A), bool), "agents_xy": np.zeros((T, B, A, 2), np.int32),
         "targets_xy": np.zeros((T, B, A, 2), np.int32), "elapsed": np.zeros((T, B), np.int32),
         "episode_done": np.zeros((T, B), bool), "metrics": np.zeros((T, B, 6), np.float32),
+        "occupancy0": np.stack([e.get_state()["occupancy"] for e in envs]),
     }
+    out["occupancy"] = np.zeros((T,) + out["occupancy0"].shape, np.uint8)  # `Grid.positions` (padded) after every step
     names = ("ISR", "CSR", "ep_length", "SoC", "makespan", "avg_throughput")
     for t in range(T):
         for b, e in enumerate(envs):
@@ -85,6 +87,7 @@ def oracle_rollout(obstacles, agents, targets, actions, *, obs_radius, collision
             out["agents_xy"][t, b] = st["agents_xy"]
             out["targets_xy"][t, b] = st["targets_xy"]
             out["elapsed"][t, b] = st["elapsed"]
+            out["occupancy"][t, b] = st["occupancy"]
             if inject_targets is not None:
                 e.set_targets(inject_targets[t, b])
     return out
@@ -126,8 +129,10 @@ def c_oracle_rollout(obstacles, agents, targets, actions, *, obs_radius, collisi
 
 def engine_rollout(obstacles, agents, targets, actions, *, obs_radius, collision_system, on_target,
                    max_episode_steps, auto_reset, seed=0, env_index_base=0, action_dtype="int64",
-                   device="cuda:0", obs_dtype=None, empty_outside=True, semantics=None, inject_targets=None):
-    """Same rollout through the HIP engine (C-ABI via pogema_amd.VecPogema); `inject_targets` as in oracle_rollout."""
+                   device="cuda:0", obs_dtype=None, empty_outside=True, semantics=None, inject_targets=None,
+                   with_occupancy=False):
+    """Same rollout through the HIP engine (C-ABI via pogema_amd.VecPogema); `inject_targets` as in oracle_rollout;
+    `with_occupancy`: also export the occupancy array (pgx_get_state) after the reset and after every step."""
     import torch
     from pogema_amd import GridConfig, VecPogema
     T, B, A = actions.shape
@@ -151,11 +156,16 @@ def engine_rollout(obstacles, agents, targets, actions, *, obs_radius, collision
         "targets_xy": np.zeros((T, B, A, 2), np.int32), "elapsed": np.zeros((T, B), np.int32),
         "episode_done": np.zeros((T, B), bool), "metrics": np.zeros((T, B, 6), np.float32),
     }
+    if with_occupancy:
+        out["occupancy0"] = env.get_state(occupancy=True)["occupancy"].cpu().numpy()
+        out["occupancy"] = np.zeros((T,) + out["occupancy0"].shape, np.uint8)
     tdt = {"int8": torch.int8, "int32": torch.int32, "int64": torch.int64}[action_dtype]
     d_actions = torch.from_numpy(actions).to(device).to(tdt)
     for t in range(T):
         obs, rew, term, trunc, infos = env.step(d_actions[t])
-        st = env.get_state()
+        st = env.get_state(occupancy=with_occupancy)
+        if with_occupancy:
+            out["occupancy"][t] = st["occupancy"].cpu().numpy()
         out["obs"][t] = obs.cpu().numpy()  # uint8 observations widen to float32 here (0/1 values: exact)
         out["rewards"][t] = rew.cpu().numpy()
         out["terminated"][t] = term.cpu().numpy()
@@ -205,7 +215,8 @@ def assert_rollouts_equal(ref, got, what=""):
     1e-6 (BASELINE.json north_star tolerance)."""
     if "metrics" in ref and "metrics" in got:  # small-integer arithmetic in float32: exact up to one rounding
         np.testing.assert_allclose(got["metrics"], ref["metrics"], rtol=1e-6, atol=1e-6, err_msg=f"{what}: metrics")
-    for key in ("agents_xy", "targets_xy", "elapsed", "terminated", "truncated", "is_active", "episode_done"):
+    for key in ("agents_xy", "targets_xy", "elapsed", "terminated", "truncated", "is_active", "episode_done", "occupancy0",
+                "occupancy"):
         if key not in ref or key not in got:
             continue
         if not np.array_equal(ref[key], got[key]):

@@ -20,8 +20,14 @@ What is recorded per case: the initial state actually used by the reference (obs
 targets_xy read back from its Grid, unpadded), the action stream, and per step agents_xy, targets_xy,
 is_active, rewards, terminated, truncated and the full float32 observations; plus the GridConfig numbers the random
 instance came from (grid_seed, density), which pin the numpy-stream instance generator (pgx_np_generate,
-Semantics.generator_rng='numpy') against the reference's.
+Semantics.generator_rng='numpy') against the reference's.  Since round 4 also: the occupancy array itself
+(`grid.positions`, padded, after reset and after every step -- settles docs/SPEC.md Q2 by data, not only through the
+observation planes) and `infos[0]['metrics']` of the step that ends the episode (Q9: the metric formulas); and one
+extra file, reference_probes.json: what the package does with an out-of-range action (Q7) and its GridConfig defaults
+(Q8) -- things no rollout of valid actions can show.  tools/pin_reference.sh runs the whole procedure and reports which
+position of every semantics switch the fixtures demand.
 """
+import json
 import argparse
 import itertools
 import os
@@ -66,6 +72,8 @@ def main():
     golden = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
     ap.add_argument("--out", default=golden, help="directory for the reference_*.npz fixtures")
     ap.add_argument("--limit", type=int, default=0, help="stop after this many cases (pipeline tests)")
+    ap.add_argument("--geoms", default="", help="comma-separated indices of the geometries to run (default: all four; "
+                                                "3 = the collision-dense one, which exercises the soft-collision switches)")
     args = ap.parse_args()
     try:
         import pogema
@@ -81,6 +89,8 @@ def main():
              dict(size=16, num_agents=8, obs_radius=5, density=0.3),
              dict(size=32, num_agents=16, obs_radius=5, density=0.3),
              dict(size=12, num_agents=40, obs_radius=2, density=0.1)]    # collision-dense
+    if args.geoms:
+        geoms = [geoms[int(i)] for i in args.geoms.split(",")]
     n = 0
     for g, cs, ot, seed in itertools.product(geoms, ("priority", "block_both", "soft"),
                                              ("finish", "restart", "nothing"), (0, 1, 2)):
@@ -100,6 +110,11 @@ def main():
         greedy = seed == 2  # one seed in three is driven towards the goals (early termination, goal-side conflicts)
         rec = dict(obs0=np.stack(obs), obs=[], rewards=[], terminated=[], truncated=[], is_active=[], agents_xy=[],
                    targets_xy=[])
+        has_positions = hasattr(grid, "positions")  # the occupancy array (padded), `Grid.positions` upstream
+        if has_positions:
+            rec["positions0"] = np.asarray(grid.positions, dtype=np.uint8).copy()
+            rec["positions"] = []
+        metrics = None
         for t in range(T):
             if greedy:
                 actions[t] = greedy_actions(obstacles, grid.get_agents_xy(ignore_borders=True),
@@ -112,15 +127,51 @@ def main():
             rec["is_active"].append([i.get("is_active", True) for i in infos])
             rec["agents_xy"].append(grid.get_agents_xy(ignore_borders=True))
             rec["targets_xy"].append(grid.get_targets_xy(ignore_borders=True))
+            if has_positions:
+                rec["positions"].append(np.asarray(grid.positions, dtype=np.uint8).copy())
+            if isinstance(infos[0], dict) and isinstance(infos[0].get("metrics"), dict):
+                metrics = (t, infos[0]["metrics"])
             if all(term) or all(trunc):
                 actions = actions[:t + 1]
                 break
+        extra = {}
+        if metrics is not None:  # names as one '|'-joined string (no pickles in the fixtures), values in the same order
+            names = sorted(metrics[1])
+            extra = dict(metrics_step=metrics[0], metrics_names="|".join(names),
+                         metrics_values=np.asarray([float(metrics[1][k]) for k in names], dtype=np.float64))
         name = f"reference_{g['size']}x{g['num_agents']}_{cs}_{ot}_s{seed}.npz"
         np.savez_compressed(os.path.join(out_dir, name), obstacles=obstacles, agents_xy0=agents0, targets_xy0=targets0,
                             actions=actions, obs_radius=r, collision_system=cs, on_target=ot,
-                            max_episode_steps=gc.max_episode_steps, grid_seed=seed, density=gc.density,
+                            max_episode_steps=gc.max_episode_steps, grid_seed=seed, density=gc.density, **extra,
                             **{k: np.asarray(v) for k, v in rec.items()})
         n += 1
+    # ---- probes: behaviour no rollout of valid actions shows -------------------------------------------------
+    probes = {"package": getattr(pogema, "__name__", "pogema"), "version": str(getattr(pogema, "__version__", "?")),
+              "standin": bool(getattr(pogema, "__standin__", False))}
+    try:  # docs/SPEC.md Q7: an action outside 0..4
+        env = pogema_v0(GridConfig(seed=0, size=8, num_agents=2, obs_radius=2, density=0.1))
+        env.reset(seed=0)
+        g0 = env.unwrapped.grid if hasattr(env, "unwrapped") else env.grid
+        before = [list(map(int, p)) for p in g0.get_agents_xy(ignore_borders=True)]
+        try:
+            env.step([7, 0])
+            after = [list(map(int, p)) for p in g0.get_agents_xy(ignore_borders=True)]
+            probes["bad_action"] = "noop" if after == before else f"moved {before} -> {after}"
+        except Exception as exc:  # noqa: BLE001
+            probes["bad_action"] = f"raises {type(exc).__name__}"
+    except Exception as exc:  # noqa: BLE001
+        probes["bad_action"] = f"probe failed: {exc!r}"
+    try:  # Q8: the defaults of GridConfig
+        d = GridConfig()
+        probes["grid_config_defaults"] = {k: (getattr(d, k) if isinstance(getattr(d, k, None), (int, float, str, bool, type(None)))
+                                              else repr(getattr(d, k, None)))
+                                          for k in ("on_target", "seed", "size", "density", "num_agents", "obs_radius",
+                                                    "collision_system", "observation_type", "max_episode_steps", "persistent",
+                                                    "empty_outside", "auto_reset", "integration")}
+    except Exception as exc:  # noqa: BLE001
+        probes["grid_config_defaults"] = f"probe failed: {exc!r}"
+    with open(os.path.join(out_dir, "reference_probes.json"), "w") as f:
+        json.dump(probes, f, indent=1, default=str)
     print(f"wrote {n} fixtures to {out_dir}")
 
 

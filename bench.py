@@ -699,6 +699,32 @@ def main(argv=None):
         except Exception as exc:  # noqa: BLE001
             extra_errors["rollout"] = repr(exc)
         torch.cuda.empty_cache()
+        obs_bytes_step = batch * agents * 3 * (2 * r + 1) ** 2 * (4 if args.obs_dtype == "float32" else 1)
+        if obs_bytes_step < (256 << 20):
+            # short launches: the same step() calls captured 32 at a time in a HIP graph and replayed -- no Python, no
+            # per-launch host work between two kernels: separates the host-bound part of `value` from the kernel
+            try:
+                import copy
+                gargs = copy.copy(args)
+                gargs.graph, gargs.buffers = 32, 0
+                gs = EngineStep(gargs, rank, device, batch, env_base, size, agents, r, world=world)
+                reps = max(1, n // 32)
+                gs.run(32 * 2)
+                g_ms = []
+                for _ in range(3):
+                    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    torch.cuda.synchronize()
+                    ev0.record()
+                    gs.run(32 * reps)
+                    ev1.record()
+                    torch.cuda.synchronize()
+                    g_ms.append(ev0.elapsed_time(ev1) / (32 * reps))
+                extras["graph"] = {"steps_per_graph": 32, "ms_per_step": statistics.median(g_ms)}
+                gs.close()
+                del gs
+            except Exception as exc:  # noqa: BLE001
+                extra_errors["graph"] = repr(exc)
+            torch.cuda.empty_cache()
         if extra_errors:
             extras["errors"] = extra_errors
 
@@ -770,7 +796,7 @@ def main(argv=None):
                          "algorithmic_bytes_per_agent_step": bpas, "algorithmic_bytes_per_launch": alg_bytes,
                          "profile_command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-default-placement "
                                             "--no-cpu-baseline --no-extras  (the default-placement window and the secondary "
-                                            "figures launch the same kernel on other buffers / half batches; profiles/r3/README.md)"},
+                                            "figures launch the same kernel on other buffers / half batches; profiles/r4/README.md)"},
         }
         if "pipelined" in extras:
             e = extras["pipelined"]
@@ -786,6 +812,14 @@ def main(argv=None):
                      what="pgx_rollout: 64 steps per launch with the actions given up front, observations into a ring of "
                           "obs_slots tensors (>= 1 GiB in total); bit-identical with 64 pgx_step calls; HIP events around the "
                           "launches")
+        if "graph" in extras:
+            e = extras["graph"]
+            e.update(value=batch * agents / (e["ms_per_step"] * 1e-3), unit="agent-steps/s",
+                     frac=alg_bytes / (e["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     host_us_per_step_in_value=round((elapsed / args.steps - e["ms_per_step"] * 1e-3) * 1e6, 2),
+                     what="the same pgx_step launches, 32 consecutive steps captured in one HIP graph (two alternating output "
+                          "sets, 32 different action tensors) and replayed: what the GPU needs per step when no host work "
+                          "lies between two launches; `value` minus this is the host-bound part of a Python step() loop")
         if "held_pair" in extras:
             e = extras["held_pair"]
             e.update(value=batch * agents / (e["ms_per_step"] * 1e-3), unit="agent-steps/s",

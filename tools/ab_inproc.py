@@ -1,5 +1,6 @@
 """Diagnostic: in-process, interleaved A/B of engine tuning knobs (PGX_FLAGS / PGX_EPW are read at pgx_create),
-so that box-to-box and warm-up drift cancel.  usage: python tools/ab_inproc.py cfg2 "PGX_FLAGS=0" "PGX_FLAGS=8" """
+so that box-to-box and warm-up drift cancel.  usage: python tools/ab_inproc.py cfg2 "PGX_FLAGS=0" "PGX_FLAGS=8"        (a variant may also name another build of
+the library: "PGX_LIB=pogema_amd/libpogema_amd_plain.so") """
 import os
 import sys
 
@@ -17,13 +18,23 @@ wl = wl.split(":")[0]
 variants = sys.argv[2:]
 batch, size, agents, r = WL[wl]
 envs = []
+from pogema_amd import _lib as _L0  # noqa: E402
+DEFAULT_LIB = _L0.LIB_PATH
 for v in variants:
-    for k in ("PGX_FLAGS", "PGX_EPW", "PGX_STAGGER", "PGX_LDS_MIN", "PGX_WAVES", "PGX_STORE", "PGX_TEAM", "PGX_STATE_STORES"):
+    for k in ("PGX_FLAGS", "PGX_EPW", "PGX_STAGGER", "PGX_LDS_MIN", "PGX_WAVES", "PGX_STORE", "PGX_TEAM", "PGX_STATE_STORES", "PGX_GATE_NS"):
         os.environ.pop(k, None)
+    lib_path = None
     for kv in v.split(","):
         if kv:
             k, val = kv.split("=")
-            os.environ[k] = val
+            if k == "PGX_LIB":  # another BUILD of the engine in the same process (e.g. make OVL=0 OUT=../libpogema_amd_plain.so)
+                lib_path = os.path.abspath(val)
+            else:
+                os.environ[k] = val
+    from pogema_amd import _lib as _L
+    want = lib_path or DEFAULT_LIB
+    if _L.LIB_PATH != want or _L._lib is None:
+        _L._lib, _L.LIB_PATH = None, want  # VecPogema keeps the library it was created with (self._lib)
     env = VecPogema(GridConfig(size=size, num_agents=agents, obs_radius=r, density=0.3, seed=0, collision_system="soft"),
                     batch=batch, auto_reset=True, reuse_buffers=True, obs_dtype=torch.uint8 if u8 else torch.float32)
     env.reset(seed=0)

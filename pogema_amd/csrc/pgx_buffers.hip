@@ -305,7 +305,7 @@ void find_other_zone(int device, size_t budget, size_t skip, std::vector<Range>&
     // A one-zone stream sustains 5.4-6.2 TB/s on the devices measured, a 1:1 two-zone stream 6.7-7.0 TB/s: a pair that
     // already reaches 6.6 TB/s straddles a zone boundary as it is -- the allocator stands in the other zone already.
     const float t_spread_abs = (float)(2.0 * (double)PROBE_HALF / 6.6e12 * 1e6);
-    if (t_same <= t_spread_abs && skip == 0) {
+    if (t_same <= t_spread_abs && skip == 0 && !getenv("PGX_ZONE_SCAN")) {  // (the scan diagnostic maps the whole budget)
         *found = true;
         return;
     }

@@ -211,6 +211,8 @@ int pgx_step(pgx_env* env, const void* actions, int action_dtype, void* obs, flo
  * the shortest launch (never worse than equal: equal is the first candidate).  Synchronises `stream`; nothing in the
  * engine's state changes.  us_equal / us_tuned (may be NULL): the pass with equal shares and with the kept ones.
  * PGX_XCD_WEIGHTS=w0,...,w7 sets the shares at pgx_create instead (diagnostic). */
+/* Both assume ONE compute partition of 8 XCDs (SPX): on any other device (pgx_geometry.xcd_aware == 0) the mapping is the
+ * identity, the shares stay equal and pgx_xcd_tune returns at once with 0 / 0. */
 int pgx_xcd_shares(pgx_env* env, int32_t* shares);
 int pgx_xcd_tune(pgx_env* env, void* obs, void* obs_alt, int32_t rounds, float* us_equal, float* us_tuned, void* stream);
 
@@ -231,7 +233,9 @@ typedef struct pgx_geometry {
     int32_t grid;           /* workgroups launched                                                                   */
     int32_t lds_bytes;      /* dynamic LDS per workgroup                                                             */
     int32_t for_rollout;    /* echo of the argument                                                                  */
-    int32_t reserved0;
+    int32_t xcd_aware;      /* 1: the device is one 8-XCD compute partition (SPX, 256 CUs): XCD-contiguous workgroup mapping,
+                               tunable per-XCD shares, cohort stagger.  0: anything else (CPX/DPX/QPX partitions, other parts):
+                               identity mapping, equal shares, no stagger, pgx_xcd_tune is a no-op -- same results        */
 } pgx_geometry;
 int pgx_get_geometry(const pgx_env* env, int32_t for_rollout, pgx_geometry* out);
 

@@ -70,7 +70,7 @@ class PgxBuffersInfo(C.Structure):
 
 class PgxGeometry(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("lanes_per_env", "waves", "envs_per_wave", "multi_wave", "p16", "stagger",
-                                          "store_policy", "state_stores", "grid", "lds_bytes", "for_rollout", "reserved0")]
+                                          "store_policy", "state_stores", "grid", "lds_bytes", "for_rollout", "xcd_aware")]
 
 
 class PgxRolloutIO(C.Structure):

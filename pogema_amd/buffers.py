@@ -126,6 +126,23 @@ class ZoneBuffers:
         _lib.check(self._lib.pgx_buffers_drop(self._handle, int(index)))
 
 
+def device_identity(device_index: int) -> str:
+    """A name for the PHYSICAL device behind `device_index` that processes with different HIP_VISIBLE_DEVICES agree on:
+    its UUID, else PCI domain:bus:device, else (no HIP device: CPU tests) the index itself."""
+    try:
+        props = torch.cuda.get_device_properties(device_index)
+        uuid = getattr(props, "uuid", None)
+        if uuid:
+            ident = f"uuid_{uuid}"
+        elif hasattr(props, "pci_bus_id"):
+            ident = f"pci_{getattr(props, 'pci_domain_id', 0)}_{props.pci_bus_id}_{getattr(props, 'pci_device_id', 0)}"
+        else:
+            ident = f"index_{device_index}"
+    except Exception:  # noqa: BLE001
+        ident = f"index_{device_index}"
+    return "".join(ch if ch.isalnum() else "_" for ch in ident)
+
+
 @contextlib.contextmanager
 def walk_lock(device_index: int, wait: bool = False):
     """One zone walk per DEVICE at a time, across processes: an exclusive flock on a per-device file in the temp dir
@@ -138,13 +155,7 @@ def walk_lock(device_index: int, wait: bool = False):
     import tempfile
     fd, held = None, True
     try:
-        try:
-            props = torch.cuda.get_device_properties(device_index)
-            ident = str(getattr(props, "uuid", None) or getattr(props, "pci_bus_id", None) or device_index)
-        except Exception:  # noqa: BLE001
-            ident = str(device_index)
-        ident = "".join(ch if ch.isalnum() else "_" for ch in ident)
-        path = os.path.join(tempfile.gettempdir(), f"pgx_zone_walk_{ident}.lock")
+        path = os.path.join(tempfile.gettempdir(), f"pgx_zone_walk_{device_identity(device_index)}.lock")
         fd = os.open(path, os.O_CREAT | os.O_RDWR, 0o666)
         try:
             fcntl.flock(fd, fcntl.LOCK_EX | (0 if wait else fcntl.LOCK_NB))

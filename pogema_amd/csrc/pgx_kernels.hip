@@ -377,8 +377,10 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
     // profiles/r2/xcd_rates.txt), so the shares need not be equal (pgx_xcd_tune): workgroup b is the (b >> 3)-th
     // of XCD b & 7 and takes slice xcd_base + (b >> 3) if that XCD still has one.
     // ASSUMPTION: blockIdx & 7 is the XCD -- true in SPX mode with 8 XCDs (round-robin dispatch of consecutive
-    // workgroups), which is how this pool's MI355X run.  In a partitioned mode (CPX/DPX ...) the mapping still covers
-    // every slice exactly once (results are unaffected); only the contiguity-per-L2 and the tuned shares lose their meaning.
+    // workgroups), which is how this pool's MI355X run.  pgx_create checks it (256 CUs in one partition) and otherwise
+    // sets bit 3 -- identity mapping, equal shares, no stagger (pgx_geometry.xcd_aware = 0): in a partitioned mode
+    // (CPX/DPX ...) the remap would still cover every slice exactly once (results are unaffected), but the
+    // contiguity-per-L2 and the tuned shares would mean nothing.
     int blk = blockIdx.x;
     if (!(p.flags & 8u)) {
         // PGX_FLAGS bits 10..12 (diagnostic): XCD x takes the share of XCD (x + rot) & 7 -- does a slow XCD stay slow?

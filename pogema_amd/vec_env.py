@@ -233,7 +233,7 @@ class VecPogema:
         multi_wave, p16, stagger, store_policy, state_stores, grid, lds_bytes."""
         g = _lib.PgxGeometry()
         _lib.check(self._lib.pgx_get_geometry(self._handle, 1 if for_rollout else 0, C.byref(g)))
-        return {n: int(getattr(g, n)) for n, _ in g._fields_ if n not in ("for_rollout", "reserved0")}
+        return {n: int(getattr(g, n)) for n, _ in g._fields_ if n != "for_rollout"}
 
     def regenerate_failures(self) -> int:
         """Envs that kept their previous instance because no fresh one could be placed (auto_reset='regenerate')."""

@@ -437,3 +437,39 @@ def test_unequal_xcd_shares_change_nothing_but_the_schedule(monkeypatch):
     assert torch.equal(buf, obs0)
     o, *_ = env.step(actions[0])
     assert torch.equal(o, ref[1])
+
+
+def test_engine_on_a_device_that_is_not_one_spx_partition(monkeypatch):
+    """the XCD-contiguous workgroup mapping, the per-XCD shares and the cohort stagger assume ONE
+    compute partition of 8 XCDs.  pgx_create checks the device (256 CUs) and otherwise falls back to the identity mapping
+    with equal shares and no stagger; PGX_ASSUME_PARTITIONED=1 forces that path here: same results, tuning is a no-op."""
+    import numpy as np
+    import torch
+    from pogema_amd import GridConfig, VecPogema
+    from util import assert_rollouts_equal, c_oracle_rollout, engine_rollout, generate_instances, random_actions
+    assert VecPogema(GridConfig(num_agents=2), batch=2).geometry()["xcd_aware"] == 1, "this pool's MI355X run SPX"
+    monkeypatch.setenv("PGX_ASSUME_PARTITIONED", "1")
+    for name, B, S, A, r in (("small_groups", 300, 16, 8, 5), ("full_wave", 40, 24, 64, 5), ("four_waves", 6, 40, 200, 7)):
+        obstacles, agents, targets = generate_instances(B, S, S, A, 0.2, 17)
+        actions = random_actions(10, B, A, 3)
+        kw = dict(obs_radius=r, collision_system="soft", on_target="restart", max_episode_steps=6, auto_reset=True, seed=4)
+        assert_rollouts_equal(c_oracle_rollout(obstacles, agents, targets, actions, nthreads=4, **kw),
+                              engine_rollout(obstacles, agents, targets, actions, **kw), f"partitioned/{name}")
+    # a launch that would get the cohort stagger and tuned shares on an SPX device
+    env = VecPogema(GridConfig(size=32, num_agents=32, obs_radius=5, density=0.2, seed=1), batch=8192, auto_reset=True,
+                    reuse_buffers=False)
+    obs, _ = env.reset(seed=1)
+    g = env.geometry()
+    assert g["xcd_aware"] == 0 and g["stagger"] == 0 and g["grid"] == -(-8192 // g["envs_per_wave"])
+    tuned = env.tune_xcd_shares(obs)
+    assert tuned["observe_us_equal_shares"] == 0.0 and tuned["xcd_shares"] == [g["grid"] // 8] * 8
+    monkeypatch.delenv("PGX_ASSUME_PARTITIONED")
+    ref = VecPogema(GridConfig(size=32, num_agents=32, obs_radius=5, density=0.2, seed=1), batch=8192, auto_reset=True,
+                    reuse_buffers=False)
+    robs, _ = ref.reset(seed=1)
+    assert ref.geometry()["xcd_aware"] == 1 and torch.equal(obs, robs)
+    acts = torch.randint(0, 5, (4, 8192, 32), device="cuda", dtype=torch.int8)
+    for t in range(4):
+        a, b = env.step(acts[t]), ref.step(acts[t])
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    env.close(); ref.close()

@@ -381,3 +381,11 @@ def test_closed_environments_leave_their_buffers_to_the_next_one(monkeypatch):
     from pogema_amd import release_cached_buffers
     release_cached_buffers()
     ref.close()
+
+
+def test_walk_lock_names_the_physical_device():
+    """The per-device walk lock must be keyed by something processes with different HIP_VISIBLE_DEVICES agree on (8 ranks
+    that all call their GPU 'device 0' must not share one lock, two processes on one GPU must)."""
+    from pogema_amd.buffers import device_identity
+    ident = device_identity(0)
+    assert ident.startswith(("uuid_", "pci_")), f"no physical identity for device 0: {ident!r}"

@@ -65,10 +65,12 @@ def test_device_reset_equals_python_oracle(cfg):
     ref = oracle_rollout(ro, ra, rt, actions, **kw)
     assert np.array_equal(obs.cpu().numpy(), ref["obs0"])
     got = {k: np.zeros_like(v) for k, v in ref.items() if k not in ("obs0",)}
+    got["occupancy0"] = env.get_state(occupancy=True)["occupancy"].cpu().numpy()
     d_act = torch.from_numpy(actions).cuda()
     for t in range(actions.shape[0]):
         o, rew, term, trunc, info = env.step(d_act[t])
-        st = env.get_state()
+        st = env.get_state(occupancy=True)
+        got["occupancy"][t] = st["occupancy"].cpu().numpy()
         got["obs"][t], got["rewards"][t] = o.cpu().numpy(), rew.cpu().numpy()
         got["terminated"][t], got["truncated"][t] = term.cpu().numpy(), trunc.cpu().numpy()
         got["is_active"][t] = info["is_active"].cpu().numpy()

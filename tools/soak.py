@@ -41,6 +41,10 @@ for on_target, collision in (("finish", "soft"), ("restart", "priority"), ("noth
                     and np.array_equal(rtr[0].astype(bool), tr_h[k].astype(bool))):
                 bad += 1
                 print(f"MISMATCH {on_target}/{collision} step {t} env {idx[k]}"); break
+        if not bad and t % 97 == 96:  # the occupancy array is STATE: observe() shows what the step showed (docs/SPEC.md Q2)
+            if not torch.equal(env.observe()[didx], obs[didx]):
+                bad += 1
+                print(f"MISMATCH {on_target}/{collision} step {t}: observe() after the step differs from the step's observation")
         if bad: break
     for o in refs: o.close()
     print(f"{on_target}/{collision}: {T} steps x {B} envs on the engine, {S} sampled envs checked at every step against the C oracle: "

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4: benches of every BASELINE workload with the box fingerprint, the headline under both walk budgets, profiles
+# benches of every BASELINE workload with the box fingerprint, the headline under both walk budgets, profiles
 O=gpurun_out/${1:-r4f}; mkdir -p $O
 bash tools/box_probe.sh $O/box.json > $O/box_probe.log 2>&1
 python bench.py > $O/bench_cfg2.json 2> $O/bench_cfg2.err

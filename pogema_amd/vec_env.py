@@ -571,8 +571,10 @@ class VecPogema:
     def _plain_obs_buffers(self, n: int, fallback: Optional[str] = None, policy: Optional[str] = None):
         """Observation buffers as torch's allocator hands them out (small tensors, probe switched off, no walk on a shared
         device, failed walk)."""
-        self.placement = {"spread": False, "method": "torch allocator", "candidates": 0, "budget_gib": 0.0,
-                          "policy": policy or ("no walk: observation tensor below 128 MiB or placement_probe off")}
+        if policy is None:
+            policy = ("the walk failed (see `fallback`): torch's allocator instead" if fallback is not None
+                      else "no walk: observation tensor below 128 MiB or placement_probe off")
+        self.placement = {"spread": False, "method": "torch allocator", "candidates": 0, "budget_gib": 0.0, "policy": policy}
         self._zone_ptrs = set()
         if fallback is not None:
             self.placement["fallback"] = fallback

@@ -21,7 +21,7 @@ envs = []
 from pogema_amd import _lib as _L0  # noqa: E402
 DEFAULT_LIB = _L0.LIB_PATH
 for v in variants:
-    for k in ("PGX_FLAGS", "PGX_EPW", "PGX_STAGGER", "PGX_LDS_MIN", "PGX_WAVES", "PGX_STORE", "PGX_TEAM", "PGX_STATE_STORES", "PGX_GATE_NS"):
+    for k in ("PGX_FLAGS", "PGX_EPW", "PGX_STAGGER", "PGX_LDS_MIN", "PGX_WAVES", "PGX_STORE", "PGX_TEAM", "PGX_STATE_STORES", "PGX_GATE_NS", "PGX_XCD_SKEW"):
         os.environ.pop(k, None)
     lib_path = None
     for kv in v.split(","):
@@ -30,19 +30,20 @@ for v in variants:
             if k == "PGX_LIB":  # another BUILD of the engine in the same process (e.g. make OVL=0 OUT=../libpogema_amd_plain.so)
                 lib_path = os.path.abspath(val)
             else:
-                os.environ[k] = val
+                os.environ[k] = val.replace(":", ",")  # (list values are written with ':' here: ',' separates the settings)
     from pogema_amd import _lib as _L
     want = lib_path or DEFAULT_LIB
     if _L.LIB_PATH != want or _L._lib is None:
         _L._lib, _L.LIB_PATH = None, want  # VecPogema keeps the library it was created with (self._lib)
     env = VecPogema(GridConfig(size=size, num_agents=agents, obs_radius=r, density=0.3, seed=0, collision_system="soft"),
-                    batch=batch, auto_reset=True, reuse_buffers=True, obs_dtype=torch.uint8 if u8 else torch.float32)
+                    batch=batch, auto_reset=True, reuse_buffers=True, obs_dtype=torch.uint8 if u8 else torch.float32,
+                    placement_probe=False if os.environ.get("AB_PLAIN_BUFFERS") == "1" else None)  # AB_PLAIN_BUFFERS=1: torch-placed buffers
     env.reset(seed=0)
     # every variant writes into the SAME pair of observation buffers: buffer placement alone moves the kernel by up to
     # 10 % (profiles/r1/placement_tiers.txt), which would otherwise drown the effect under test
     if envs:
         env._bufs = [(envs[0]._bufs[k][0],) + env._alloc_outputs(False)[1:] for k in range(2)]
-        if batch >= 2048:  # like the first variant: its own XCD shares, tuned on the shared buffers
+        if batch >= 2048 and os.environ.get("AB_PLAIN_BUFFERS") != "1":  # like the first variant: its own XCD shares, tuned on the shared buffers
             env.tune_xcd_shares(env._bufs[0][0], env._bufs[1][0])
     else:
         env._outputs()

@@ -42,6 +42,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+OBS_BYTES = {"float32": 4, "bfloat16": 2, "float16": 2, "uint8": 1}  # bytes per observation cell
+
+
+def _torch_obs_dtype(name):
+    import torch
+    return {"float32": torch.float32, "bfloat16": torch.bfloat16, "float16": torch.float16, "uint8": torch.uint8}[name]
+
+
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 WORKLOADS = {
@@ -286,7 +294,7 @@ def build_env(args, device, batch, env_base, size, agents, r, placement_probe=Tr
                      # (--graph: the captured steps need fixed buffers -> two alternating sets)
                      reuse_buffers={0: True if args.graph > 0 else "recycle", 1: "single", 2: True}[args.buffers]
                      if buffers is None else buffers,
-                     obs_dtype=torch.float32 if args.obs_dtype == "float32" else torch.uint8,
+                     obs_dtype=_torch_obs_dtype(args.obs_dtype),
                      placement_probe=placement_probe,
                      placement_budget_gib=placement_budget(args, world))
 
@@ -413,7 +421,7 @@ class PipelinedStep:
                         max_episode_steps=args.max_episode_steps)
         self.env = PipelinedVecPogema(gc, batch=batch, device=device, parts=parts, env_index_base=env_base, auto_reset=True,
                                       reuse_buffers=True, placement_budget_gib=placement_budget(args),
-                                      obs_dtype=torch.float32 if args.obs_dtype == "float32" else torch.uint8)
+                                      obs_dtype=_torch_obs_dtype(args.obs_dtype))
         self.env.reset(seed=0)
         self.env.warm_buffers()
         tdt = {"int8": torch.int8, "int32": torch.int32, "int64": torch.int64}[args.action_dtype]
@@ -459,14 +467,14 @@ class RolloutStep:
                         max_episode_steps=args.max_episode_steps)
         self.env = VecPogema(gc, batch=batch, device=device, env_index_base=env_base, auto_reset=True,
                              placement_budget_gib=placement_budget(args),
-                             obs_dtype=torch.float32 if args.obs_dtype == "float32" else torch.uint8)
+                             obs_dtype=_torch_obs_dtype(args.obs_dtype))
         self.env.reset(seed=0)
         tdt = {"int8": torch.int8, "int32": torch.int32, "int64": torch.int64}[args.action_dtype]
         gen = torch.Generator(device=device)
         gen.manual_seed(1 + rank)
         self.actions = torch.randint(0, 5, (k, batch, agents), generator=gen, device=device).to(tdt)
         # ring of at least 1 GiB (and at least two slots): a smaller one would sit partly in the 256 MiB Infinity Cache
-        obs_bytes = batch * agents * 3 * (2 * r + 1) ** 2 * (4 if args.obs_dtype == "float32" else 1)
+        obs_bytes = batch * agents * 3 * (2 * r + 1) ** 2 * OBS_BYTES[args.obs_dtype]
         self.slots = min(k, max(2, -(-(1 << 30) // obs_bytes)))
 
     def measure(self, steps, windows=3):
@@ -524,8 +532,9 @@ def make_parser():
     ap.add_argument("--max-episode-steps", type=int, default=64)
     ap.add_argument("--action-dtype", default="int8", choices=["int8", "int32", "int64"],
                     help="int8 = the 1 byte/agent of SURVEY 8(d)'s formula; wider dtypes are budgeted at their width")
-    ap.add_argument("--obs-dtype", default="float32", choices=["float32", "uint8"],
-                    help="float32 = the reference's dtype (the headline); uint8 = the engine's lighter non-drop-in mode")
+    ap.add_argument("--obs-dtype", default="float32", choices=sorted(OBS_BYTES),
+                    help="float32 = the reference's dtype (the headline); bfloat16 / float16 / uint8 = the engine's lighter "
+                         "non-drop-in formats (the same 0/1 planes in 2 / 2 / 1 bytes per cell)")
     ap.add_argument("--auto-reset", default="restore", choices=["restore", "regenerate"],
                     help="restore = finished envs return to their initial state inside the step kernel (headline); "
                          "regenerate = they get a fresh random instance on the device (pgx_regenerate)")
@@ -699,7 +708,7 @@ def main(argv=None):
         except Exception as exc:  # noqa: BLE001
             extra_errors["rollout"] = repr(exc)
         torch.cuda.empty_cache()
-        obs_bytes_step = batch * agents * 3 * (2 * r + 1) ** 2 * (4 if args.obs_dtype == "float32" else 1)
+        obs_bytes_step = batch * agents * 3 * (2 * r + 1) ** 2 * OBS_BYTES[args.obs_dtype]
         if obs_bytes_step < (256 << 20):
             # short launches: the same step() calls captured 32 at a time in a HIP graph and replayed -- no Python, no
             # per-launch host work between two kernels: separates the host-bound part of `value` from the kernel
@@ -732,7 +741,7 @@ def main(argv=None):
         n_agent_steps = total_envs * agents * args.steps
         value = n_agent_steps / elapsed
         abytes = {"int8": 1, "int32": 4, "int64": 8}[args.action_dtype]
-        bpas = algorithmic_bytes_per_agent_step(size, agents, r, 4 if args.obs_dtype == "float32" else 1, abytes)
+        bpas = algorithmic_bytes_per_agent_step(size, agents, r, OBS_BYTES[args.obs_dtype], abytes)
         alg_bytes = bpas * batch * agents  # per launch (this GPU's shard)
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None
@@ -740,7 +749,7 @@ def main(argv=None):
         if os.path.exists(pmc):
             try:
                 with open(pmc) as f:
-                    key = f"{args.workload}/{args.collision}" + ("" if args.obs_dtype == "float32" else "/uint8")
+                    key = f"{args.workload}/{args.collision}" + ("" if args.obs_dtype == "float32" else "/" + args.obs_dtype)
                     traffic = json.load(f).get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None

@@ -89,10 +89,14 @@ extern "C" {
 #define PGX_ACTION_I64 2
 
 /* dtype of the observation buffer (pgx_config.obs_dtype).  F32 is the reference's dtype (gymnasium Box float32) and
- * the drop-in default; U8 writes the same 0/1 planes one byte per cell -- a 4x lighter, non-drop-in mode for callers
- * that cast on their side. */
+ * the drop-in default; the others write the same 0/1 planes in a lighter format -- non-drop-in modes for callers whose
+ * policy network does not want float32 anyway: U8 one byte per cell (4x lighter; the caller casts), BF16 / F16 two bytes
+ * per cell (2x lighter, consumed directly by a mixed-precision network: no cast pass at all -- uint8 plus a cast to
+ * bfloat16 on the consumer's side moves as many HBM bytes as float32 did).  0.0 and 1.0 are exact in every format. */
 #define PGX_OBS_F32 0
 #define PGX_OBS_U8 1
+#define PGX_OBS_BF16 2
+#define PGX_OBS_F16 3
 
 /* hard limits of this build */
 #define PGX_MAX_OBS_RADIUS 15   /* window side 2r+1 <= 31 (one 32-bit row mask per window row) */
@@ -111,7 +115,7 @@ typedef struct pgx_config {
     int32_t max_episode_steps; /* MultiTimeLimit; <= 0 disables truncation        */
     int32_t auto_reset;        /* 1: an env whose agents are all terminated or truncated is   */
                                /*    reset to its stored initial state inside the same step    */
-    int32_t obs_dtype;         /* PGX_OBS_* (0 = float32, the reference's dtype)                 */
+    int32_t obs_dtype;         /* PGX_OBS_* (0 = float32, the reference's dtype; 1 u8, 2 bf16, 3 f16) */
     uint64_t seed;             /* lifelong (restart) target stream seed                        */
     int64_t env_index_base;    /* global index of env 0 of this shard (keeps lifelong streams  */
                                /* independent of how the batch is sharded over devices)        */
@@ -194,7 +198,7 @@ int pgx_get_map(pgx_env* env, uint8_t* obstacles, void* stream);
  * `MultiTimeLimit.step` (upstream pogema/envs.py, pogema/grid.py,
  * pogema/wrappers/multi_time_limit.py).
  *   actions      device [batch, agents] of action_dtype, values 0..4 (noop, up, down, left, right)
- *   obs          device f32 (or u8 when obs_dtype = PGX_OBS_U8) [batch, agents, 3, 2r+1, 2r+1]
+ *   obs          device f32 (or u8 / bf16 / f16, per pgx_config.obs_dtype) [batch, agents, 3, 2r+1, 2r+1]
  *                (obstacles, agents, target)                                               may be NULL
  *   rewards      device f32 [batch, agents]
  *   terminated   device u8  [batch, agents]

@@ -24,7 +24,13 @@ BAD_ACTIONS = {"noop": 0, "flag": 1}
 LIFELONG_RNGS = {"build": 0, "numpy": 1}
 def _obs_dtypes():
     import torch
-    return {torch.float32: 0, torch.uint8: 1}
+    return {torch.float32: 0, torch.uint8: 1, torch.bfloat16: 2, torch.float16: 3}
+
+
+def obs_elem_bytes(dtype) -> int:
+    """Bytes per observation cell for a torch dtype the engine writes (float32 4, bfloat16 / float16 2, uint8 1)."""
+    import torch
+    return {torch.float32: 4, torch.bfloat16: 2, torch.float16: 2, torch.uint8: 1}[dtype]
 
 
 class _LazyObsDtypes(dict):

@@ -20,7 +20,8 @@ import torch
 
 from . import _lib
 
-_TYPESTR = {torch.float32: "<f4", torch.uint8: "|u1"}
+# (numpy's array interface has no bfloat16: such a buffer is wrapped as float16 and re-viewed, same item size)
+_TYPESTR = {torch.float32: "<f4", torch.uint8: "|u1", torch.float16: "<f2", torch.bfloat16: "<f2"}
 
 
 class _Owner:
@@ -76,7 +77,7 @@ class ZoneBuffers:
         elif max_spacer_gib == "all":
             max_spacer_gib = float(os.environ.get("PGX_ZONE_SPACER_GIB", self.ALL_GIB))
         lib = _lib.load()
-        nbytes = int(np.prod(shape)) * (4 if dtype == torch.float32 else 1)
+        nbytes = int(np.prod(shape)) * _lib.obs_elem_bytes(dtype)
         handle = C.c_void_p()
         torch.cuda.synchronize(index)  # the search times kernels (on a private stream): nothing else should be running
         _lib.check(lib.pgx_buffers_create_at(index, nbytes, int(count), float(skip_gib), float(max_spacer_gib), C.byref(handle)))
@@ -95,28 +96,30 @@ class ZoneBuffers:
             t = torch.as_tensor(_Cai(ptr, shape, _TYPESTR[dtype], self._owner), device=torch.device("cuda", index))
             if t.data_ptr() != ptr:
                 raise RuntimeError("torch copied the zone buffer instead of wrapping it")
+            if t.dtype != dtype:
+                t = t.view(dtype)
             self.tensors.append(t)
         # all buffers lie in one virtual range at a constant stride: the pool as ONE [count, *shape] tensor whose first
         # axis steps by that stride (the observation ring of VecPogema.rollout)
         self.stride_bytes = int(lib.pgx_buffers_stride(handle))
-        item = 4 if dtype == torch.float32 else 1
+        item = _lib.obs_elem_bytes(dtype)
         dense = [item]
         for n in reversed(tuple(shape)[1:]):
             dense.insert(0, dense[0] * n)
         self._lib, self._handle = lib, handle
-        self._view = (tuple(shape), _TYPESTR[dtype], tuple(dense), item, torch.device("cuda", index))
+        self._view = (tuple(shape), _TYPESTR[dtype], tuple(dense), item, torch.device("cuda", index), dtype)
         self.ring = self.ring_view(0, count)
 
     def ring_view(self, start: int, count: int) -> torch.Tensor:
         """Buffers start .. start+count-1 as one [count, *shape] tensor (first axis strided by `stride_bytes`)."""
-        shape, typestr, dense, item, dev = self._view
+        shape, typestr, dense, item, dev, dtype = self._view
         ptr = self._lib.pgx_buffers_ptr(self._handle, int(start))
         if not ptr or start + count > len(self.tensors):
             raise IndexError("ring_view outside the pool")
         ring = torch.as_tensor(_Cai(ptr, (count,) + shape, typestr, self._owner, strides=(self.stride_bytes,) + dense), device=dev)
         if ring.data_ptr() != ptr or ring.stride(0) * item != self.stride_bytes:
             raise RuntimeError("torch copied the zone buffers instead of wrapping them")
-        return ring
+        return ring if ring.dtype == dtype else ring.view(dtype)
 
     def drop(self, index: int):
         """Release the memory of buffer `index` (pgx_buffers_drop).  The caller must have dropped every reference to

@@ -117,6 +117,10 @@ struct pgx_env {
 // ================================================================================================
 extern "C" {
 
+static int obs_elem_bytes(int obs_dtype) {
+    return obs_dtype == PGX_OBS_U8 ? 1 : (obs_dtype == PGX_OBS_BF16 || obs_dtype == PGX_OBS_F16) ? 2 : 4;
+}
+
 int pgx_abi_version(void) { return PGX_ABI_VERSION; }
 
 const char* pgx_last_error(void) { return g_err.c_str(); }
@@ -151,7 +155,7 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
         cfg->soft_occupancy < 0 || cfg->soft_occupancy > 1 || cfg->reserved0 != 0)
         return fail(PGX_E_INVALID, "unknown semantics switch (soft_vertex_rule %d, coop_reward %d, bad_action %d, soft_occupancy %d)",
                     cfg->soft_vertex_rule, cfg->coop_reward, cfg->bad_action, cfg->soft_occupancy);
-    if (cfg->obs_dtype != PGX_OBS_F32 && cfg->obs_dtype != PGX_OBS_U8)
+    if (cfg->obs_dtype < PGX_OBS_F32 || cfg->obs_dtype > PGX_OBS_F16)
         return fail(PGX_E_INVALID, "unknown obs_dtype %d", cfg->obs_dtype);
     if ((int64_t)cfg->num_agents > (int64_t)cfg->height * cfg->width)
         return fail(PGX_E_INVALID, "more agents than cells");
@@ -173,10 +177,10 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
     int waves_override = 0;  // PGX_WAVES: 1 = single-wave kernel for A <= 64 whatever the launch size, k = k helper waves
     if (const char* f = getenv("PGX_WAVES")) waves_override = atoi(f);
     e->geo = pgx::step_geometry(cfg->batch, A, e->bmw, e->W, !(e->flags & 2u), epw_override,
-                                cfg->obs_dtype == PGX_OBS_U8 ? 1 : 4, waves_override);
+                                obs_elem_bytes(cfg->obs_dtype), waves_override);
     // pgx_rollout's launch shape: the same, minus the helper waves of large launches (step_geometry())
     e->geo_roll = pgx::step_geometry(cfg->batch, A, e->bmw, e->W, !(e->flags & 2u), epw_override,
-                                     cfg->obs_dtype == PGX_OBS_U8 ? 1 : 4, waves_override, true);
+                                     obs_elem_bytes(cfg->obs_dtype), waves_override, true);
     for (pgx::StepGeometry* g : {&e->geo, &e->geo_roll}) {
         if (const char* f = getenv("PGX_STAGGER")) g->stagger = atoi(f);  // tuning/diagnostic override
         if (const char* f = getenv("PGX_STORE")) {  // tuning/diagnostic override: plain | nt | sc1
@@ -631,6 +635,7 @@ static void fill_params(const pgx_env* e, pgx::StepParams& p) {
         p.xcd_base[x] = e->geo.xcd_base[x];
     }
     p.obs_u8 = e->cfg.obs_dtype == PGX_OBS_U8 ? 1 : 0;
+    p.obs_one = e->cfg.obs_dtype == PGX_OBS_BF16 ? 0x3F80u : e->cfg.obs_dtype == PGX_OBS_F16 ? 0x3C00u : 0u;
     p.soft_rule = c.soft_vertex_rule;
     p.soft_occupancy = c.soft_occupancy;
     p.coop_reward = c.coop_reward;
@@ -710,7 +715,7 @@ int pgx_rollout(pgx_env* e, int32_t steps, const pgx_rollout_io* io, void* strea
     rp.actions_stride = agents * action_bytes[io->action_dtype];
     rp.agents_stride = agents;
     rp.envs_stride = e->cfg.batch;
-    rp.obs_stride = agents * 3 * W * W * (p.obs_u8 ? 1 : 4);
+    rp.obs_stride = agents * 3 * W * W * (int64_t)obs_elem_bytes(e->cfg.obs_dtype);
     rp.policy_seed = io->policy_seed;
     rp.policy_step0 = io->policy_step0;
     rp.actions_out = io->actions ? nullptr : io->actions_out;

@@ -69,6 +69,7 @@ struct StepParams {
     int32_t mode, collision, on_target, max_steps, auto_reset, action_dtype;
     int32_t epw;       // environments per wave (single-wave blocks, num_agents <= 64)
     int32_t obs_u8;    // 1: `obs` is uint8 (one byte per cell) instead of float32
+    uint32_t obs_one;  // != 0: `obs` is a 16-bit float format and this is its bit pattern of 1.0 (bfloat16 0x3F80, float16 0x3C00)
     int32_t stagger;   // cohort stagger of the single-wave kernel (StepGeometry::stagger)
     int32_t store_policy;  // observation stores: 0 plain, 1 nontemporal, 2 sc1 write-through (StepGeometry::store_policy)
     int32_t state_stores;  // when the small per-step result stores are issued: 0 at once, 1 after the LDS barrier, 2 after the stream

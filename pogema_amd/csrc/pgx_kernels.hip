@@ -254,6 +254,51 @@ __device__ __forceinline__ void stream_obs_u8(uint8_t* out, size_t base, int n, 
     else loop(std::false_type{});
 }
 
+// 16-bit float observation stream (obs_dtype = PGX_OBS_BF16 / PGX_OBS_F16; NOT the drop-in dtype): the same 0/1 planes as
+// bfloat16 or float16, what a mixed-precision policy network consumes directly -- half the HBM bytes of float32 with no
+// cast kernel on the consumer's side (uint8 + a cast to bf16 moves as many bytes as float32 did).  `one` is the bit
+// pattern of 1.0 (0x3F80 / 0x3C00).  8 cells per lane per 16-byte store, funnelled out of ceil(8/W)+1 row masks; a pair
+// of cells becomes one 32-bit word with ONE multiply: bits 0 and 16 times `one` (no carry: one < 2^16).
+template <typename RowBits>
+__device__ __forceinline__ void stream_obs_h16(uint16_t* out, size_t base, int n, int W, uint32_t magic, int tid, int NT,
+                                               bool nontemporal, uint32_t one, RowBits row_bits, int wave = 0, int nw = 1) {
+    uint16_t* o = out + base;
+    const int head = min(n, (int)((8 - (base & 7)) & 7));
+    const int nvec = (n - head) >> 3;
+    const int tail0 = head + (nvec << 3);
+    if (tid < 16) {  // unaligned head / tail cells
+        const int e = (tid < 8) ? tid : tail0 + (tid - 8);
+        const bool mine = (tid < 8) ? (tid < head) : (e < n);
+        if (mine) {
+            const int row = (int)__umulhi((uint32_t)e, magic);
+            o[e] = (uint16_t)(((row_bits(row) >> (e - row * W)) & 1u) * one);
+        }
+    }
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4* out4 = reinterpret_cast<u32x4*>(o + head);
+    const int part = (nvec + nw - 1) / nw;  // nw > 1: every wave streams its own contiguous part (as stream_obs_u8)
+    const int q0 = nw > 1 ? wave * part + (tid & 63) : tid, q1 = nw > 1 ? min(nvec, (wave + 1) * part) : nvec;
+    const int qs = nw > 1 ? 64 : NT;
+    auto loop = [&](auto nt_tag) {
+        for (int q = q0; q < q1; q += qs) {
+            const int e0 = head + (q << 3);
+            int row = (int)__umulhi((uint32_t)e0, magic);
+            const int col = e0 - row * W;
+            uint32_t m = row_bits(row) >> col;
+            for (int have = W - col; have < 8; have += W) m |= row_bits(++row) << have;
+            u32x4 v;
+            v.x = ((m & 1u) | ((m & 2u) << 15)) * one;
+            v.y = (((m >> 2) & 1u) | (((m >> 2) & 2u) << 15)) * one;
+            v.z = (((m >> 4) & 1u) | (((m >> 4) & 2u) << 15)) * one;
+            v.w = (((m >> 6) & 1u) | (((m >> 6) & 2u) << 15)) * one;
+            if constexpr (decltype(nt_tag)::value) __builtin_nontemporal_store(v, &out4[q]);
+            else out4[q] = v;
+        }
+    };
+    if (nontemporal) loop(std::true_type{});
+    else loop(std::false_type{});
+}
+
 // ---- P16 float32 stream (window side <= 16): the slice's (agent, channel, window row) masks sit in LDS as packed u16
 // (`rows16`, two per word, four zero halfwords behind the last one); a float4 at flat offset e needs the bits of rows
 // e / W and e / W + 1 (one ds_read2_b32).  `stream_rows16_span` writes the float4s q0, q0 + qs, ... < q1 (index 0 =
@@ -313,6 +358,32 @@ __device__ __forceinline__ void stream_rows16_loop(f32x4_t* out4, const uint32_t
         }
     }
 }
+// The same walk for the 16-bit float formats (8 cells = 16 bytes per lane-store; window side >= 7, so that 8 consecutive
+// cells never span more than two rows): (row, col) kept incrementally, the row pair funnelled out of one ds_read2_b32.
+template <int POLICY>
+__device__ __forceinline__ void stream_rows16_loop_h16(f32x4_t* out4, const uint32_t* rows32, int W, int row, int col, int q0,
+                                                       int q1, int qs, uint32_t one) {
+    const int drow = (8 * qs) / W, dcol = 8 * qs - drow * W;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    for (int q = q0; q < q1; q += qs) {
+        const uint32_t w0 = rows32[row >> 1], w1 = rows32[(row >> 1) + 1];
+        const uint32_t pair = (uint32_t)((((uint64_t)w1 << 32) | w0) >> (16 * (row & 1)));
+        const uint32_t m = ((pair & 0xFFFFu) >> col) | ((pair >> 16) << (W - col));
+        u32x4 v;
+        v.x = ((m & 1u) | ((m & 2u) << 15)) * one;
+        v.y = (((m >> 2) & 1u) | (((m >> 2) & 2u) << 15)) * one;
+        v.z = (((m >> 4) & 1u) | (((m >> 4) & 2u) << 15)) * one;
+        v.w = (((m >> 6) & 1u) | (((m >> 6) & 2u) << 15)) * one;
+        store_obs16(&out4[q], __builtin_bit_cast(f32x4_t, v), (uint32_t)POLICY);
+        col += dcol;
+        row += drow;
+        if (col >= W) {
+            col -= W;
+            row += 1;
+        }
+    }
+}
+
 template <bool PIPE>
 __device__ __forceinline__ void stream_rows16_span(f32x4_t* out4, const uint32_t* rows32, int head, int W, uint32_t magic,
                                                    uint32_t spol, int q0, int q1, int qs, int last_word) {
@@ -854,6 +925,43 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
         // ---- phase 4 (P16): stream the observations --------------------------------------------------------
         const int n = nag * 3 * W * W;
         const size_t base = (size_t)env0 * A * 3 * W * W;
+        if constexpr (WT == 0) {  // (the lighter formats run the run-time-W instance: keeps the float32 instances lean)
+        if (p.obs_one && W >= 7) {  // bfloat16 / float16 planes, the fast walk (8 cells span at most two rows)
+            uint16_t* o = reinterpret_cast<uint16_t*>(obs_out) + base;
+            const int head = min(n, (int)((8 - (base & 7)) & 7));
+            const int nvec = (n - head) >> 3;
+            const int tail0 = head + (nvec << 3);
+            if (tid < 16) {  // unaligned head / tail cells
+                const int e = (tid < 8) ? tid : tail0 + (tid - 8);
+                if ((tid < 8) ? (tid < head) : (e < n)) {
+                    const int row = (int)__umulhi((uint32_t)e, p.w_magic);
+                    o[e] = (uint16_t)((((uint32_t)rows16[row] >> (e - row * W)) & 1u) * p.obs_one);
+                }
+            }
+            const bool span = MW && !(p.flags & 512u);
+            const int part = (nvec + nw - 1) / nw;
+            const int q0 = span ? wave * part + lane : tid, q1 = span ? min(nvec, (wave + 1) * part) : nvec;
+            const int e0 = head + (q0 << 3);
+            const int row0 = (int)__umulhi((uint32_t)e0, p.w_magic);
+            f32x4_t* out4 = reinterpret_cast<f32x4_t*>(o + head);
+            const uint32_t* rows32 = reinterpret_cast<const uint32_t*>(rows16);
+            const int qs = span ? 64 : NT;
+            if (q0 < q1) {
+                if (p.store_policy == 0) stream_rows16_loop_h16<0>(out4, rows32, W, row0, e0 - row0 * W, q0, q1, qs, p.obs_one);
+                else if (p.store_policy == 1) stream_rows16_loop_h16<1>(out4, rows32, W, row0, e0 - row0 * W, q0, q1, qs, p.obs_one);
+                else stream_rows16_loop_h16<2>(out4, rows32, W, row0, e0 - row0 * W, q0, q1, qs, p.obs_one);
+            }
+            if (when_stores == 2) emit_state(pos, tgt, active, elapsed, macc, so);
+            return;
+        }
+        if (p.obs_one) {  // ... window sides below 7: the generic funnel
+            const int nrows = nag * 3 * W;
+            stream_obs_h16(reinterpret_cast<uint16_t*>(obs_out), base, n, W, p.w_magic, tid, NT, p.store_policy == 1, p.obs_one,
+                           [&](int row) -> uint32_t { return row < nrows ? (uint32_t)rows16[row] : 0u; }, wave,
+                           (MW && !(p.flags & 512u)) ? nw : 1);
+            if (when_stores == 2) emit_state(pos, tgt, active, elapsed, macc, so);
+            return;
+        }
         if (p.obs_u8) {
             if (dbg && !dbg2 && tid == 0) p.dbg[(size_t)blk * 4 + 2] = wall_clock64();
             const int nrows = nag * 3 * W;
@@ -866,6 +974,7 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
                 p.dbg[(size_t)blk * 4 + 3] = wall_clock64();
             }
             return;
+        }
         }
         float* out = obs_out + base;
         const int head = min(n, (int)((4 - (base & 3)) & 3));
@@ -893,7 +1002,7 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
         return;
         };
         // (the rollout kernels keep the run-time form: they are at their register limit as it is)
-        if (ROLL) p16_phases(std::integral_constant<int, 0>{});
+        if (ROLL || p.obs_u8 || p.obs_one) p16_phases(std::integral_constant<int, 0>{});
         else if (W_rt == 11) p16_phases(std::integral_constant<int, 11>{});
         else if (W_rt == 15) p16_phases(std::integral_constant<int, 15>{});
         else if (W_rt == 7) p16_phases(std::integral_constant<int, 7>{});
@@ -937,6 +1046,14 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
     lds_sync<MW>();
 
     // ---- phase 4: stream the observations, 16 bytes per lane per store ---------------------------------
+    if (p.obs_one) {
+        const int nrows = nag * 3 * W;
+        stream_obs_h16(reinterpret_cast<uint16_t*>(obs_out), (size_t)env0 * A * 3 * W * W, nrows * W, W, p.w_magic, tid, NT,
+                       p.store_policy == 1, p.obs_one, [&](int row) -> uint32_t { return row < nrows ? s_rows[row] : 0u; }, wave,
+                       (MW && !(p.flags & 512u)) ? nw : 1);
+        if (when_stores == 2) emit_state(pos, tgt, active, elapsed, macc, so);
+        return;
+    }
     if (p.obs_u8) {
         const int nrows = nag * 3 * W;
         stream_obs_u8(reinterpret_cast<uint8_t*>(obs_out), (size_t)env0 * A * 3 * W * W, nrows * W, W, p.w_magic, tid, NT,
@@ -1191,7 +1308,10 @@ StepGeometry step_geometry(int batch, int A, int bmw, int W, bool allow_p16, int
         // configs[2] 123.6 -> 118.8 us (2 waves 123.9, 4 waves 145), batch 4096: 84.8 -> 82.8, batch 2048: 49.0 -> 44.5;
         // worse for batch 1024 (26.0 -> 27.8), for 32- and 16-agent environments, for uint8 observations and inside a
         // rollout launch (whose waves drift apart anyway: 114.6 -> 118.9), which keep one wave.
-        if (helpers == 1 && !for_rollout && A > 32 && batch >= 2048 && obs_elem_bytes == 4 && env_stream >= 64 * 1024)
+        // (the 16-bit float formats likewise -- same cells, half the bytes: configs[2] bfloat16 68.4 -> 63.3 us,
+        // gpurun r4r/bf16_waves_cfg2.txt; uint8 46.2 -> 52.7: stays on one wave)
+        if (helpers == 1 && !for_rollout && A > 32 && batch >= 2048 && obs_elem_bytes >= 2 &&
+            env_stream * (size_t)(4 / obs_elem_bytes) >= 64 * 1024)
             helpers = 3;
         if (waves_override == 1) helpers = 1;
         else if (waves_override > 1) helpers = waves_override > 16 ? 16 : waves_override;

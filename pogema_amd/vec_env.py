@@ -146,10 +146,11 @@ class VecPogema:
             raise ValueError("placement_budget_gib must be None, 'half', 'all' or a number of GiB >= 0")
         self.placement_budget_gib = placement_budget_gib
         self._zone_ptrs = set()   # data_ptr() of the observation buffers that come from a zone pool
-        # float32 is the reference's observation dtype (gymnasium Box float32) and the default; torch.uint8 writes
-        # the same 0/1 planes one byte per cell (4x fewer HBM bytes per step) for callers that cast on their side
+        # float32 is the reference's observation dtype (gymnasium Box float32) and the default.  The same 0/1 planes in a
+        # lighter format, for callers whose policy does not want float32 anyway: torch.bfloat16 / torch.float16 (half the
+        # HBM bytes per step, consumed directly by a mixed-precision network), torch.uint8 (a quarter; the caller casts)
         if obs_dtype not in _lib.OBS_DTYPES:
-            raise ValueError(f"obs_dtype must be torch.float32 or torch.uint8, got {obs_dtype}")
+            raise ValueError(f"obs_dtype must be torch.float32, torch.bfloat16, torch.float16 or torch.uint8, got {obs_dtype}")
         self.obs_dtype = obs_dtype
         self._seed = gc.seed
         cfg = _lib.PgxConfig(
@@ -203,7 +204,7 @@ class VecPogema:
             from .buffers import ParkedBuffers
             try:
                 torch.cuda.current_stream(self.device).synchronize()  # nothing of this engine may still be writing
-                n = self._recycle_sets(int(np.prod(self.obs_shape)) * (4 if self.obs_dtype == torch.float32 else 1))
+                n = self._recycle_sets(int(np.prod(self.obs_shape)) * _lib.obs_elem_bytes(self.obs_dtype))
                 ParkedBuffers.park(self._shelf_key(), rec.retire(), pl, n)  # only zone-pool buffers, only a whole set
             except Exception:
                 pass
@@ -481,7 +482,7 @@ class VecPogema:
         return half, "auto: the device looks exclusively ours -> half of the free memory", False
 
     def _pick_obs_buffers(self, n: Optional[int] = None):
-        obs_bytes = int(np.prod(self.obs_shape)) * (4 if self.obs_dtype == torch.float32 else 1)
+        obs_bytes = int(np.prod(self.obs_shape)) * _lib.obs_elem_bytes(self.obs_dtype)
         if n is None:
             n = 1 if self.single_buffer else 2
         if not self.placement_probe or obs_bytes < self.PLACEMENT_MIN_BYTES:
@@ -597,7 +598,7 @@ class VecPogema:
         from .buffers import RecyclingOutputs
         if not RecyclingOutputs.available():
             return False
-        obs_bytes = int(np.prod(self.obs_shape)) * (4 if self.obs_dtype == torch.float32 else 1)
+        obs_bytes = int(np.prod(self.obs_shape)) * _lib.obs_elem_bytes(self.obs_dtype)
         n = self._recycle_sets(obs_bytes)
         if not self.placement_probe or obs_bytes < self.PLACEMENT_MIN_BYTES:
             bufs = self._plain_obs_buffers(n)  # torch's own memory, XCD shares tuned for launches of >= 2048 envs
@@ -806,7 +807,7 @@ class VecPogema:
         dev, BA = self.device, (K, self.batch, self.num_agents)
         obs, slot_stride = None, 0
         if slots:
-            obs_bytes = int(np.prod(self.obs_shape)) * (4 if self.obs_dtype == torch.float32 else 1)
+            obs_bytes = int(np.prod(self.obs_shape)) * _lib.obs_elem_bytes(self.obs_dtype)
             if self.placement_probe and slots <= 8 and obs_bytes >= self.PLACEMENT_MIN_BYTES:
                 if slots not in self._rollout_pools:  # decided once per ring size (None = no ring: dense torch memory)
                     self._rollout_pools[slots] = self._build_rollout_ring(slots, obs_bytes)

@@ -45,6 +45,7 @@ def test_config_struct_layout():
     ("on_target", -1, "on_target"), ("height", 0, "map size"), ("width", 4096, "map size"),
     ("soft_vertex_rule", 2, "semantics"), ("coop_reward", -1, "semantics"), ("bad_action", 3, "semantics"),
     ("lifelong_rng", 2, "semantics"), ("soft_occupancy", 2, "semantics"), ("reserved0", 1, "semantics"),
+    ("obs_dtype", 4, "obs_dtype"), ("obs_dtype", -1, "obs_dtype"),
 ])
 def test_create_rejects_bad_config(engine_lib, field, value, needle):
     cfg = _lib.PgxConfig(batch=4, height=8, width=8, num_agents=2, obs_radius=3, collision_system=0, on_target=0,

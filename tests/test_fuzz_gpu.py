@@ -27,7 +27,7 @@ def _random_case(rng):
     return dict(B=B, H=H, W=Wd, A=A, r=r, density=density, collision=str(rng.choice(COLLISIONS)),
                 on_target=str(rng.choice(ON_TARGET)), max_steps=int(rng.integers(1, 12)),
                 auto_reset=bool(rng.integers(0, 2)), T=int(rng.integers(3, 20)),
-                action_dtype=str(rng.choice(["int8", "int32", "int64"])), u8=bool(rng.integers(0, 2)),
+                action_dtype=str(rng.choice(["int8", "int32", "int64"])), u8=str(rng.choice(["", "", "uint8", "uint8", "bfloat16", "float16"])),
                 seed=int(rng.integers(0, 2 ** 31)), base=int(rng.integers(0, 1000)),
                 soft_vertex=str(rng.choice(["lowest_index", "all_stay"])), coop_reward=str(rng.choice(["all_solved", "per_agent"])),
                 soft_occupancy=str(rng.choice(["exact", "index_order"])),
@@ -69,11 +69,11 @@ def test_random_configurations(chunk):
                                                                      soft_occupancy=c["soft_occupancy"]))
         ref = c_oracle_rollout(o, a, t, actions, nthreads=4, **kw)
         got = engine_rollout(o, a, t, actions, action_dtype=c["action_dtype"],
-                             obs_dtype=torch.uint8 if c["u8"] else None, **kw)
+                             obs_dtype=getattr(torch, c["u8"]) if c["u8"] else None, **kw)
         assert_rollouts_equal(ref, got, f"fuzz chunk {chunk}: {c}")
         # ... and the same episode as ONE launch (pgx_rollout)
         got = engine_rollout_launch(o, a, t, actions, action_dtype=c["action_dtype"],
-                                    obs_dtype=torch.uint8 if c["u8"] else None, **kw)
+                                    obs_dtype=getattr(torch, c["u8"]) if c["u8"] else None, **kw)
         assert_rollouts_equal(ref, got, f"fuzz chunk {chunk} as one rollout launch: {c}")
         done += 1
 

@@ -95,6 +95,43 @@ def test_uint8_observations(geom):
     assert_rollouts_equal(ref, got, f"u8/{name}")
 
 
+@pytest.mark.parametrize("fmt", ["bfloat16", "float16"])
+@pytest.mark.parametrize("geom", U8_GEOMS, ids=[g[0] for g in U8_GEOMS])
+def test_half_precision_observations(geom, fmt):
+    """obs_dtype=torch.bfloat16 / torch.float16 (2x lighter, non-drop-in formats a mixed-precision policy consumes
+    directly): the same 0/1 planes, two bytes per cell, exact in both formats -- every window width class (W = 3 .. 31),
+    ragged tails and unaligned slice starts, single- and multi-wave environments, both row-mask paths; step by step and as
+    one rollout launch (observation ring of 2); into zone-pool buffers (numpy's array interface has no bfloat16)."""
+    import torch
+    from util import engine_rollout_launch
+    dtype = getattr(torch, fmt)
+    name, B, H, Wd, A, r, density, T, max_steps = geom
+    seed = zlib.crc32(f"h16/{name}".encode()) % (2 ** 31)
+    obstacles, agents, targets = generate_instances(B, H, Wd, A, density, seed)
+    actions = random_actions(T, B, A, seed + 1)
+    kw = dict(obs_radius=r, collision_system="soft", on_target="restart", max_episode_steps=max_steps, auto_reset=True)
+    ref = oracle_rollout(obstacles, agents, targets, actions, **kw)
+    got = engine_rollout(obstacles, agents, targets, actions, obs_dtype=dtype, **kw)
+    assert_rollouts_equal(ref, got, f"{fmt}/{name}")
+    got = engine_rollout_launch(obstacles, agents, targets, actions, obs_dtype=dtype, **kw)
+    assert_rollouts_equal(ref, got, f"{fmt}/{name} as one rollout launch")
+    if name == "full_wave":
+        from pogema_amd import GridConfig, VecPogema
+        gc = GridConfig(map=obstacles[0].tolist(), num_agents=A, obs_radius=r, collision_system="soft", on_target="restart",
+                        max_episode_steps=max_steps)
+        env = VecPogema(gc, batch=B, auto_reset=True, obs_dtype=dtype, reuse_buffers=True, placement_budget_gib=2.0)
+        env.PLACEMENT_MIN_BYTES = 1  # force the zone pool for this small tensor
+        first = env.reset_from_state(obstacles, agents, targets)
+        assert first.dtype == dtype and np.array_equal(first.float().cpu().numpy(), ref["obs0"])
+        for t in range(3):
+            obs = env.step(torch.from_numpy(actions[t]).cuda())[0]
+            assert obs.dtype == dtype and np.array_equal(obs.float().cpu().numpy(), ref["obs"][t])
+        assert env.placement["method"].startswith("pgx_buffers")
+        ring = env.rollout(torch.from_numpy(actions[3:7]).cuda(), obs_slots=2)["obs"]
+        assert ring.dtype == dtype and np.array_equal(ring[1].float().cpu().numpy(), ref["obs"][6])
+        env.close(release=True)
+
+
 @pytest.mark.parametrize("geom", [g for g in GEOMETRIES if g[0] in ("baseline_cfg1", "odd_agents", "two_slots", "max_radius")],
                          ids=lambda g: g[0])
 def test_random_outside(geom):

@@ -149,7 +149,7 @@ def engine_rollout(obstacles, agents, targets, actions, *, obs_radius, collision
         assert obs0.dtype == obs_dtype
     W = 2 * obs_radius + 1
     out = {
-        "obs0": obs0.cpu().numpy(),
+        "obs0": obs0.float().cpu().numpy() if obs0.dtype != torch.uint8 else obs0.cpu().numpy(),
         "obs": np.zeros((T, B, A, 3, W, W), np.float32), "rewards": np.zeros((T, B, A), np.float32),
         "terminated": np.zeros((T, B, A), bool), "truncated": np.zeros((T, B, A), bool),
         "is_active": np.zeros((T, B, A), bool), "agents_xy": np.zeros((T, B, A, 2), np.int32),
@@ -166,7 +166,7 @@ def engine_rollout(obstacles, agents, targets, actions, *, obs_radius, collision
         st = env.get_state(occupancy=with_occupancy)
         if with_occupancy:
             out["occupancy"][t] = st["occupancy"].cpu().numpy()
-        out["obs"][t] = obs.cpu().numpy()  # uint8 observations widen to float32 here (0/1 values: exact)
+        out["obs"][t] = obs.float().cpu().numpy()  # uint8 / bfloat16 / float16 observations widen to float32 here (0/1: exact)
         out["rewards"][t] = rew.cpu().numpy()
         out["terminated"][t] = term.cpu().numpy()
         out["truncated"][t] = trunc.cpu().numpy()
@@ -200,7 +200,7 @@ def engine_rollout_launch(obstacles, agents, targets, actions, *, obs_radius, co
     tdt = {"int8": torch.int8, "int32": torch.int32, "int64": torch.int64}[action_dtype]
     res = env.rollout(torch.from_numpy(actions).to(device).to(tdt))
     done = res["episode_done"].cpu().numpy()
-    out = {"obs0": obs0.cpu().numpy(), "obs": res["obs"].cpu().numpy().astype(np.float32),
+    out = {"obs0": obs0.float().cpu().numpy(), "obs": res["obs"].float().cpu().numpy(),
            "rewards": res["rewards"].cpu().numpy(), "terminated": res["terminated"].cpu().numpy(),
            "truncated": res["truncated"].cpu().numpy(), "is_active": res["is_active"].cpu().numpy(), "episode_done": done,
            "metrics": np.where(done[..., None], res["metrics"].cpu().numpy(), 0)}

@@ -13,7 +13,8 @@ from pogema_amd import GridConfig, VecPogema  # noqa: E402
 WL = {"cfg1": (1024, 16, 8, 5), "cfg2": (8192, 64, 64, 5), "cfg3": (8192, 32, 16, 5), "cfg4": (4096, 256, 256, 7),
       "a8big": (65536, 16, 8, 5), "a32": (8192, 32, 32, 5), "a32big": (32768, 32, 32, 5), "a24small": (512, 32, 24, 5), "half": (4096, 64, 64, 5), "three_q": (6144, 64, 64, 5), "quarter": (2048, 64, 64, 5), "eighth": (1024, 64, 64, 5)}
 wl = sys.argv[1]
-u8 = wl.endswith(":u8")
+fmt = wl.split(":")[1] if ":" in wl else "float32"   # cfg2:u8, cfg2:bfloat16, cfg2:float16
+odt = {"float32": torch.float32, "u8": torch.uint8, "uint8": torch.uint8, "bfloat16": torch.bfloat16, "float16": torch.float16}[fmt]
 wl = wl.split(":")[0]
 variants = sys.argv[2:]
 batch, size, agents, r = WL[wl]
@@ -36,7 +37,7 @@ for v in variants:
     if _L.LIB_PATH != want or _L._lib is None:
         _L._lib, _L.LIB_PATH = None, want  # VecPogema keeps the library it was created with (self._lib)
     env = VecPogema(GridConfig(size=size, num_agents=agents, obs_radius=r, density=0.3, seed=0, collision_system="soft"),
-                    batch=batch, auto_reset=True, reuse_buffers=True, obs_dtype=torch.uint8 if u8 else torch.float32,
+                    batch=batch, auto_reset=True, reuse_buffers=True, obs_dtype=odt,
                     placement_probe=False if os.environ.get("AB_PLAIN_BUFFERS") == "1" else None)  # AB_PLAIN_BUFFERS=1: torch-placed buffers
     env.reset(seed=0)
     # every variant writes into the SAME pair of observation buffers: buffer placement alone moves the kernel by up to

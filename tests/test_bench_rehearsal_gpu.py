@@ -85,3 +85,17 @@ def test_single_rank_through_rccl():
     assert line["metric"].startswith("agent-steps/sec (whole node), 64-agent 64x64 grid")
     assert len(line["roofline"]["kernel_ms_per_rank"]) == 1
     assert 0.3 < line["roofline"]["frac"] < 1.0
+
+
+def test_eight_ranks_configs3_at_its_stated_size():
+    """BASELINE configs[3] exactly as stated -- 65536 envs sharded over EIGHT ranks (strong scaling, shard_bounds) -- with
+    eight real processes and engines, all on the one device of the box: the launch the driver's 8-GPU node will see, minus
+    the seven other GPUs."""
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--workload", "cfg3", "--global-batch", "65536"] + QUICK,
+                       capture_output=True, text=True, timeout=900, env=_env(PGX_BENCH_SHARE_DEVICE="1"))
+    line = _line(p)
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["metric"].startswith("REHEARSAL (8 ranks share")
+    assert line["config"]["global_batch"] == 65536 and line["config"]["envs_per_gpu"] == 8192
+    per_rank = line["roofline"]["kernel_ms_per_rank"]
+    assert len(per_rank) == 8 and all(k > 0 for k in per_rank)
+    assert line["value"] == pytest.approx(65536 * 16 * 40 / (line["ms_per_step"] * 40 * 1e-3), rel=1e-6)

@@ -473,3 +473,38 @@ def test_engine_on_a_device_that_is_not_one_spx_partition(monkeypatch):
         a, b = env.step(acts[t]), ref.step(acts[t])
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     env.close(); ref.close()
+
+
+@pytest.mark.parametrize("fmt", ["bfloat16", "float16", "uint8"])
+def test_light_formats_on_every_observation_path(fmt):
+    """The non-drop-in observation formats go through every call that writes observations, not only step(): observe(),
+    observe(out=), step(out=), the masked observe of auto_reset='regenerate', reset_where -- each equal to the float32
+    engine's tensor cast to the format."""
+    import torch
+    from pogema_amd import GridConfig, VecPogema
+    dtype = getattr(torch, fmt)
+    gc = GridConfig(size=20, num_agents=24, obs_radius=4, density=0.25, seed=3, collision_system="soft", max_episode_steps=5)
+    B = 300
+    a = VecPogema(gc, batch=B, auto_reset="regenerate", obs_dtype=dtype)
+    b = VecPogema(gc, batch=B, auto_reset="regenerate")
+    oa, _ = a.reset(seed=11)
+    ob, _ = b.reset(seed=11)
+    assert oa.dtype == dtype and torch.equal(oa.float(), ob)
+    mine = (torch.empty(a.obs_shape, dtype=dtype, device="cuda"), torch.empty((B, 24), device="cuda"),
+            torch.empty((B, 24), dtype=torch.bool, device="cuda"), torch.empty((B, 24), dtype=torch.bool, device="cuda"),
+            torch.empty((B, 24), dtype=torch.bool, device="cuda"))
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    for t in range(12):  # max_episode_steps 5: two rounds of on-device regeneration with rewritten observations
+        acts = torch.randint(0, 5, (B, 24), generator=gen, device="cuda", dtype=torch.int8)
+        xa = a.step(acts, out=mine) if t % 2 else a.step(acts)
+        xb = b.step(acts)
+        assert xa[0].dtype == dtype and torch.equal(xa[0].float(), xb[0]), f"step {t}"
+        assert torch.equal(xa[1], xb[1]) and torch.equal(xa[4]["episode_done"], xb[4]["episode_done"])
+    assert torch.equal(a.observe().float(), b.observe())
+    scratch = torch.zeros(a.obs_shape, dtype=dtype, device="cuda")
+    assert a.observe(out=scratch) is scratch and torch.equal(scratch.float(), b.observe())
+    mask = torch.arange(B, device="cuda") % 3 == 0
+    assert torch.equal(a.reset_where(mask, seed=5).float(), b.reset_where(mask, seed=5))
+    with pytest.raises(ValueError):
+        a.observe(out=torch.zeros(a.obs_shape, device="cuda"))  # float32 buffer for a bfloat16 engine
+    a.close(); b.close()

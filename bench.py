@@ -840,8 +840,12 @@ def main(argv=None):
             line["secondary"] = extras
         line["box"] = fingerprint
         if world == 1 and not args.no_cpu_baseline and not args.stub:
-            line["cpu_baseline"] = cpu_baseline(size, agents, r, args.collision, args.density, args.max_episode_steps,
-                                                args.cpu_seconds)
+            try:  # the baseline leg must never cost the measured line
+                line["cpu_baseline"] = cpu_baseline(size, agents, r, args.collision, args.density, args.max_episode_steps,
+                                                    args.cpu_seconds)
+            except Exception as exc:  # noqa: BLE001
+                line["cpu_baseline"] = {"value": None, "unit": "agent-steps/s", "cores": 0, "kind": "port",
+                                        "sample": f"FAILED: {exc!r}"}
         print(json.dumps(line), flush=True)
     step.close()
     if use_dist:

@@ -576,6 +576,7 @@ def main(argv=None):
             raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; they must agree")
 
     fingerprint = box_fingerprint() if rank == 0 else None  # plain sysfs reads, before anything touches the GPU
+    group_note = None
 
     import torch
     import torch.distributed as dist
@@ -601,10 +602,19 @@ def main(argv=None):
             else:
                 if "MASTER_PORT" not in os.environ:  # PGX_BENCH_FORCE_DIST without a launcher
                     os.environ.update(MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
-                dist.init_process_group("nccl", device_id=device)
+                try:
+                    dist.init_process_group("nccl", device_id=device)
+                except Exception as exc:  # noqa: BLE001
+                    # RCCL carries nothing but the clock (two 8-byte collectives per window): if it cannot be brought up
+                    # on this box the run is still a measurement -- gloo with host tensors, and the line says so
+                    print(f"bench.py: RCCL init failed on rank {rank} ({exc!r}); using gloo for the barriers and the clock",
+                          file=sys.stderr)
+                    group_note = f"gloo (RCCL init failed: {exc!r})"
+                    dist.init_process_group("gloo", rank=rank, world_size=world)
     use_dist = dist.is_initialized()
     rehearsal = (not args.stub) and share_device() and world > torch.cuda.device_count()
-    comm_device = torch.device("cpu") if (args.stub or rehearsal) else device  # where the clock / kernel-time tensors live
+    # where the clock / kernel-time tensors live: on the device for RCCL, on the host for gloo
+    comm_device = torch.device("cpu") if (args.stub or rehearsal or (use_dist and dist.get_backend() == "gloo")) else device
 
     from pogema_amd.sharding import shard_bounds
     per_gpu, size, agents, r = WORKLOADS[args.workload]
@@ -784,7 +794,7 @@ def main(argv=None):
                        "action_dtype": args.action_dtype, "envs_per_gpu": batch, "global_batch": total_envs,
                        "sharding": f"batch-sharded x{world}, no collective",
                        "rehearsal": bool(rehearsal),
-                       "process_group": (dist.get_backend() if use_dist else None),
+                       "process_group": (group_note or dist.get_backend()) if use_dist else None,
                        "launch": f"hipGraph of {args.graph} steps" if args.graph > 0 else "one pgx_step launch per step",
                        "obs_buffers": step.describe_buffers()},
             "roofline": {"bound": "hbm" if (args.buffers != 1 or alg_bytes > (200 << 20)) else "hbm (output tensor rewritten in place: largely Infinity-Cache resident)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

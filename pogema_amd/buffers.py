@@ -67,7 +67,7 @@ class ZoneBuffers:
         free, _total = torch.cuda.mem_get_info(index)
         return min(ZoneBuffers.ALL_GIB, 0.5 * free / float(1 << 30))
 
-    def __init__(self, shape, dtype, device, count=2, max_spacer_gib=None, skip_gib=0.0):
+    def __init__(self, shape, dtype, device, count=2, max_spacer_gib=None, skip_gib=0.0, sync_device=True):
         if dtype not in _TYPESTR:
             raise ValueError(f"unsupported dtype {dtype}")
         dev = torch.device(device)
@@ -79,7 +79,8 @@ class ZoneBuffers:
         lib = _lib.load()
         nbytes = int(np.prod(shape)) * _lib.obs_elem_bytes(dtype)
         handle = C.c_void_p()
-        torch.cuda.synchronize(index)  # the search times kernels (on a private stream): nothing else should be running
+        if sync_device:
+            torch.cuda.synchronize(index)  # the search times kernels (on a private stream): nothing else should be running
         _lib.check(lib.pgx_buffers_create_at(index, nbytes, int(count), float(skip_gib), float(max_spacer_gib), C.byref(handle)))
         self._owner = _Owner(lib, handle)
         info = _lib.PgxBuffersInfo()

@@ -74,8 +74,11 @@ class VecPogema:
     one (`placement_budget_gib`, `placement["policy"]` says what happened):
       None (default)  only a process that evidently has the device to itself: >= 90 % of its memory free AND no other
                       process walking it right now (a per-device file lock) -- then half of the free memory.  On a
-                      shared or already loaded device there is NO walk, no timing allocations, no cache flush: the
-                      buffers are plain torch memory (recycled all the same; 15-25 % slower steps on configs[2]).
+                      shared or already loaded device NOTHING is held: the engine only probes whether the allocator
+                      happens to stand between two zones right now (one 768 MiB probe pair for a few milliseconds, no
+                      spacers, no timing tensors, no cache flush, no device-wide synchronisation) and builds its buffers
+                      there if so -- true for about three processes in four on this pool -- else they are plain torch
+                      memory (recycled all the same; 15-25 % slower steps on configs[2]).
       "half" / a number of GiB / "all"   an explicit request: walk with that budget wherever you are
                       ("all" = everything but the engine's 10 % reserve: a process that owns the device).
       0               never walk.
@@ -460,6 +463,7 @@ class VecPogema:
     PLACEMENT_MIN_BYTES = int(os.environ.get("PGX_ZONE_MIN_MB", "128")) << 20
 
     EXCLUSIVE_FREE_FRACTION = 0.90
+    PROBE_ONLY_GIB = 0.01  # a budget below one spacer: pgx_buffers_create times its first probe pair and walks nowhere
 
     def _walk_policy(self):
         """-> (GiB the zone walk may hold; 0 = no walk, why, explicit?) -- class docstring, `placement_budget_gib`."""
@@ -477,8 +481,8 @@ class VecPogema:
         if env is not None:
             return float(env), f"PGX_ZONE_SPACER_GIB={env}", True
         if free < self.EXCLUSIVE_FREE_FRACTION * total:
-            return 0.0, (f"no walk: device {self.device_index} is shared or already loaded ({100.0 * free / total:.0f} % of its "
-                         f"memory free, < {100 * self.EXCLUSIVE_FREE_FRACTION:.0f} %)"), False
+            return self.PROBE_ONLY_GIB, (f"probe only, nothing held: device {self.device_index} is shared or already loaded "
+                                         f"({100.0 * free / total:.0f} % of its memory free, < {100 * self.EXCLUSIVE_FREE_FRACTION:.0f} %)"), False
         return half, "auto: the device looks exclusively ours -> half of the free memory", False
 
     def _pick_obs_buffers(self, n: Optional[int] = None):
@@ -491,14 +495,38 @@ class VecPogema:
         budget, why, explicit = self._walk_policy()
         if budget <= 0.0:
             return self._plain_obs_buffers(n, policy=why)
+        if budget < 1.0:
+            return self._probe_only_obs_buffers(n, why)
         with walk_lock(self.device_index, wait=explicit) as mine:
             if not mine:  # somebody else is walking this device right now: it is not ours alone
-                return self._plain_obs_buffers(n, policy=f"no walk: another process is walking device {self.device_index}")
+                return self._probe_only_obs_buffers(n, f"probe only, nothing held: another process is walking device {self.device_index}")
             self._budget_now = budget
             bufs = self._pick_obs_buffers_walk(n, obs_bytes)
             if self.placement is not None:
                 self.placement.setdefault("policy", why)
             return bufs
+
+    def _probe_only_obs_buffers(self, n: int, why: str):
+        """The co-tenant-safe form of the placement (a shared or loaded device): exactly the n buffers the engine needs, built
+        where the allocator stands, after ONE probe pair told whether that spot straddles two zones -- no spacers, no spare
+        buffers, no timing tensors, no cache flush, no device-wide synchronisation.  Zone buffers if it does, torch's own
+        memory if not."""
+        from .buffers import ZoneBuffers
+        try:
+            pool = ZoneBuffers(self.obs_shape, self.obs_dtype, self.device, count=n, max_spacer_gib=self.PROBE_ONLY_GIB,
+                               sync_device=False)
+        except _lib.PgxError as e:
+            return self._plain_obs_buffers(n, fallback=str(e), policy=why)
+        if not pool.info["spread"]:
+            del pool
+            return self._plain_obs_buffers(n, policy=why + " -- the allocator does not stand between two zones")
+        self.placement = dict(pool.info, method="pgx_buffers (two HBM zones per buffer)", pools_tried=1, policy=why,
+                              chosen=["zone"] * n)
+        bufs = list(pool.tensors)
+        self._zone_ptrs = {t.data_ptr() for t in bufs}
+        if self.batch >= 2048 and self._has_state():
+            self.placement.update(self.tune_xcd_shares(bufs[0], bufs[-1] if n > 1 else None))
+        return bufs
 
     def _pick_obs_buffers_walk(self, n: int, obs_bytes: int):
         # The walk's verdict does not always carry over to the real buffers (halves may straddle a boundary), and some
@@ -566,8 +594,9 @@ class VecPogema:
 
     def _zone_pool(self, count: int, skip_gib: float = 0.0):
         from .buffers import ZoneBuffers
-        return ZoneBuffers(self.obs_shape, self.obs_dtype, self.device, count=count,
-                           max_spacer_gib=getattr(self, "_budget_now", 0.0), skip_gib=skip_gib)
+        budget = getattr(self, "_budget_now", 0.0)
+        return ZoneBuffers(self.obs_shape, self.obs_dtype, self.device, count=count, max_spacer_gib=budget, skip_gib=skip_gib,
+                           sync_device=budget >= 1.0)  # (probe-only budgets: no device-wide synchronisation either)
 
     def _plain_obs_buffers(self, n: int, fallback: Optional[str] = None, policy: Optional[str] = None):
         """Observation buffers as torch's allocator hands them out (small tensors, probe switched off, no walk on a shared
@@ -855,8 +884,8 @@ class VecPogema:
             if self.placement is None:
                 self.placement = {"spread": False, "method": "torch allocator", "candidates": 0, "budget_gib": 0.0, "policy": why}
             return None
-        with walk_lock(self.device_index, wait=explicit) as mine:
-            if not mine:
+        with walk_lock(self.device_index, wait=explicit and budget >= 1.0) as mine:
+            if not mine and budget >= 1.0:
                 return None
             self._budget_now = budget
             retry = float(os.environ.get("PGX_POOL_RETRY", "1.10"))
@@ -875,6 +904,13 @@ class VecPogema:
                     pool, times, start = cand, ct, cs
                 info = cand.info
                 del cand
+                if budget < 1.0 and not info["spread"]:  # probe only, and the allocator does not stand between two zones
+                    del pool
+                    self.placement = {"spread": False, "method": "torch allocator", "candidates": 0, "budget_gib": 0.0,
+                                      "policy": why + " -- the allocator does not stand between two zones"}
+                    return None
+                if budget < 1.0:
+                    break
                 if (not info["spread"] or info["final_us"] <= 0 or
                         max(times[start:start + slots]) <= retry * info["final_us"] * obs_bytes / (2 * (384 << 20))):
                     break

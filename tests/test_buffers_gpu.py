@@ -238,8 +238,9 @@ def test_recycle_mode_small_tensors_and_missing_hook(monkeypatch):
 
 def test_default_policy_walks_only_on_a_device_that_is_ours(monkeypatch):
     """placement_budget_gib=None (the default) must not hold half of a SHARED device.  The walk runs only when
-    >= 90 % of the device's memory is free and nobody else is walking it; otherwise there is no walk, no timing
-    allocations, no cache flush -- plain torch buffers, recycled all the same -- and `placement["policy"]` says why."""
+    >= 90 % of the device's memory is free and nobody else is walking it; otherwise NOTHING is held: one probe pair tells
+    whether the allocator happens to stand between two zones (then the n buffers are built there), no spacers, no spare
+    buffers, no timing tensors, no cache flush, no device-wide synchronisation -- and `placement["policy"]` says so."""
     import torch
     from pogema_amd import GridConfig, VecPogema, buffers
     cfg = GridConfig(size=32, num_agents=32, obs_radius=5, density=0.3, seed=5)
@@ -255,17 +256,37 @@ def test_default_policy_walks_only_on_a_device_that_is_ours(monkeypatch):
         return orig_pool(self, count, skip_gib)
 
     monkeypatch.setattr(VecPogema, "_zone_pool", counting_pool)
-    flushes = []
+    flushes, syncs, probes = [], [], []
     monkeypatch.setattr(torch.cuda, "empty_cache", lambda: flushes.append(1))
+    real_sync = torch.cuda.synchronize
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: (syncs.append(1), real_sync(*a, **k))[1])
+    real_zone = buffers.ZoneBuffers.__init__
+
+    def spying_zone(self, shape, dtype, device, count=2, max_spacer_gib=None, skip_gib=0.0, sync_device=True):
+        probes.append((count, max_spacer_gib, sync_device))
+        return real_zone(self, shape, dtype, device, count=count, max_spacer_gib=max_spacer_gib, skip_gib=skip_gib,
+                         sync_device=sync_device)
+
+    monkeypatch.setattr(buffers.ZoneBuffers, "__init__", spying_zone)
     # (1) a loaded / shared device: 60 % free
     monkeypatch.setattr(torch.cuda, "mem_get_info", lambda *a: (int(0.6 * total), total))
     env = VecPogema(cfg, batch=B, auto_reset=True)
-    env.reset(seed=5)
+    syncs_before = len(syncs)
+    env.reset(seed=5)  # (the output buffers are picked here: the first observation needs one)
     obs = env.step(acts)[0]
-    assert not walks and not flushes and env.placement["method"] == "torch allocator"
-    assert "shared or already loaded" in env.placement["policy"] and env.placement["budget_gib"] == 0.0
+    # exactly the 2 buffers it needs, a probe-only budget, no device-wide synchronisation, no walk, no flush
+    assert probes == [(2, VecPogema.PROBE_ONLY_GIB, False)] and not walks and not flushes and len(syncs) == syncs_before
+    pl = env.placement
+    assert pl["policy"].startswith("probe only, nothing held") and "shared or already loaded" in pl["policy"]
+    assert pl["candidates"] == 0 and (pl.get("spacer_gib") or 0.0) == 0.0
+    assert pl["method"] == ("pgx_buffers (two HBM zones per buffer)" if pl["spread"] else "torch allocator")
     assert env._recycler and len(env._recycler) == 2 and obs.data_ptr() in set(env._recycler.obs_pointers())
-    env.close()
+    ref = VecPogema(cfg, batch=B, auto_reset=True, reuse_buffers=False, placement_budget_gib=0)
+    ref.reset(seed=5)
+    assert torch.equal(ref.step(acts)[0], obs)
+    ref.close()
+    env.close(release=True)  # (a zone set found by the probe would otherwise be taken over by the next case without a walk)
+    del probes[:]
     # (2) the same, but the caller asks: explicit budgets walk wherever they are
     env = VecPogema(cfg, batch=B, auto_reset=True, placement_budget_gib=2.0)
     env.reset(seed=5)
@@ -280,7 +301,8 @@ def test_default_policy_walks_only_on_a_device_that_is_ours(monkeypatch):
         env = VecPogema(cfg, batch=B, auto_reset=True)
         env.reset(seed=5)
         assert not walks and "another process is walking" in env.placement["policy"]
-        env.close()
+        assert env.placement["policy"].startswith("probe only, nothing held") and probes[-1] == (2, VecPogema.PROBE_ONLY_GIB, False)
+        env.close(release=True)
     # (4) an empty device and nobody else: the walk runs with half of the free memory
     env = VecPogema(cfg, batch=B, auto_reset=True)
     env.reset(seed=5)

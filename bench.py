@@ -793,6 +793,9 @@ def main(argv=None):
                        "max_episode_steps": args.max_episode_steps, "obs_dtype": args.obs_dtype,
                        "action_dtype": args.action_dtype, "envs_per_gpu": batch, "global_batch": total_envs,
                        "sharding": f"batch-sharded x{world}, no collective",
+                       "semantics": None if args.stub else {k: getattr(step.env.semantics, k) for k in
+                                                                ("soft_vertex", "soft_occupancy", "coop_reward", "bad_action",
+                                                                 "lifelong_rng", "generator_rng")},
                        "rehearsal": bool(rehearsal),
                        "process_group": (group_note or dist.get_backend()) if use_dist else None,
                        "launch": f"hipGraph of {args.graph} steps" if args.graph > 0 else "one pgx_step launch per step",

@@ -14,6 +14,8 @@ TXT="${OUT%.json}.txt"
   timeout 60 rocm-smi --showmemorypartition --showcomputepartition 2>&1 | grep -v "^=\|^$" | head -20
   echo "== rocm-smi ids / vram / firmware"
   timeout 60 rocm-smi --showuniqueid --showmeminfo vram --showvbios --showbus 2>&1 | grep -v "^=\|^$" | head -30
+  echo "== rocm-smi temperatures / power (idle: the probe runs before the benchmark)"
+  timeout 60 rocm-smi --showtemp --showpower 2>&1 | grep -i "temperature\|power" | head -12
   echo "== rocm-smi clocks"
   timeout 60 rocm-smi --showclocks 2>&1 | grep -i "sclk\|mclk\|fclk\|socclk" | head -12
   if command -v amd-smi >/dev/null 2>&1; then

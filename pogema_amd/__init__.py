@@ -15,8 +15,9 @@ def release_cached_buffers() -> None:
     """Gives back the zone-spread observation buffers that closed environments left mapped for their successors
     (pogema_amd.buffers.ParkedBuffers: at most PGX_POOL_CACHE_MB, default 2.5 GiB) -- for callers who close an
     environment to make room for something else."""
-    from .buffers import ParkedBuffers
+    from .buffers import ParkedBuffers, WalkVerdicts
     ParkedBuffers.clear()
+    WalkVerdicts.clear()  # ... and the next engine may walk the device again
 
 
 def __getattr__(name):

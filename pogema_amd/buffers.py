@@ -147,6 +147,30 @@ def device_identity(device_index: int) -> str:
     return "".join(ch if ch.isalnum() else "_" for ch in ident)
 
 
+def _open_lock_file(path: str):
+    """The per-device lock file as an fd, or None.  Shared temp dirs are hostile ground: never follow a
+    symlink planted under the predictable name, make a file we create usable by every tenant (mode 0666 whatever the
+    umask), and when another user's file cannot be opened for writing open it read-only -- flock works on that too."""
+    flags = getattr(os, "O_NOFOLLOW", 0) | getattr(os, "O_CLOEXEC", 0)
+    try:
+        fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_RDWR | flags, 0o666)
+        try:
+            os.fchmod(fd, 0o666)
+        except OSError:
+            pass
+        return fd
+    except FileExistsError:
+        pass
+    except OSError:
+        return None
+    for mode in (os.O_RDWR, os.O_RDONLY):
+        try:
+            return os.open(path, mode | flags)
+        except OSError:
+            continue
+    return None
+
+
 @contextlib.contextmanager
 def walk_lock(device_index: int, wait: bool = False):
     """One zone walk per DEVICE at a time, across processes: an exclusive flock on a per-device file in the temp dir
@@ -154,28 +178,84 @@ def walk_lock(device_index: int, wait: bool = False):
     when this process holds the lock.  wait=False (the default policy): a busy lock means another process is walking the
     device right now, i.e. the device is shared -- yields False at once and the caller skips its walk (workers
     that start together must not each hold half of the free memory).  wait=True (an explicit budget): block until free,
-    because two concurrent walks perturb each other's timings.  Never raises: without a usable lock file it yields True."""
+    because two concurrent walks perturb each other's timings.  Never raises.  A lock file that cannot be used at all
+    (another tenant's unreadable file, a symlink, a read-only temp dir) means "cannot tell whether the device is ours":
+    the default policy then does NOT walk (yields False -> probe only), an explicit budget walks unlocked as asked."""
     import fcntl
     import tempfile
     fd, held = None, True
     try:
         path = os.path.join(tempfile.gettempdir(), f"pgx_zone_walk_{device_identity(device_index)}.lock")
-        fd = os.open(path, os.O_CREAT | os.O_RDWR, 0o666)
-        try:
-            fcntl.flock(fd, fcntl.LOCK_EX | (0 if wait else fcntl.LOCK_NB))
-        except BlockingIOError:
-            held = False
-    except OSError:
-        fd = None  # no lock file (read-only temp dir ...): behave as before
+        fd = _open_lock_file(path)
+        if fd is None:
+            held = bool(wait)
+        else:
+            try:
+                fcntl.flock(fd, fcntl.LOCK_EX | (0 if wait else fcntl.LOCK_NB))
+            except BlockingIOError:
+                held = False
+            except OSError:
+                held = bool(wait)
+    except Exception:  # noqa: BLE001
+        fd, held = None, bool(wait)
+    locked = fd is not None and held
     try:
         yield held
     finally:
         if fd is not None:
             try:
-                if held:
+                if locked:
                     fcntl.flock(fd, fcntl.LOCK_UN)
+            except OSError:
+                pass
             finally:
                 os.close(fd)
+
+
+class WalkVerdicts:
+    """Negative cache of the zone walk, per (process, PHYSICAL device): once a walk that used its whole budget has found
+    no second zone on a device, later engines of this process do not repeat it (a failed walk holds half of
+    the free memory for seconds, and bench.py alone builds four engines) -- they go straight to the probe-only placement.
+    Only failures are remembered here (successes live on the ParkedBuffers shelf); a later request with a LARGER budget
+    than the one that failed may walk again.  Keyed by `device_identity`, so the verdict follows the GPU, not the index.
+    PGX_WALK_NEGATIVE_CACHE=0 switches it off; `clear()` (= pogema_amd.release_cached_buffers()) forgets everything."""
+
+    _lock = threading.Lock()
+    _failed = {}  # device identity -> {"budget_gib", "candidates", "same_zone_us", "spacer_gib", "walks"}
+    walks = 0     # statistics: full walks this process has run (any outcome), for tests and bench lines
+
+    @staticmethod
+    def enabled() -> bool:
+        return os.environ.get("PGX_WALK_NEGATIVE_CACHE", "1") not in ("", "0")
+
+    @classmethod
+    def note_walk(cls, device_index: int, info: dict, budget_gib: float):
+        """Record the outcome of a walk (`info` = ZoneBuffers.info of its first pool)."""
+        with cls._lock:
+            cls.walks += 1
+            if info.get("spread"):
+                cls._failed.pop(device_identity(device_index), None)
+                return
+            key = device_identity(device_index)
+            prev = cls._failed.get(key)
+            cls._failed[key] = {"budget_gib": max(float(budget_gib), prev["budget_gib"] if prev else 0.0),
+                                "candidates": int(info.get("candidates", 0)), "same_zone_us": info.get("same_zone_us"),
+                                "spacer_gib": info.get("spacer_gib"), "walks": (prev["walks"] if prev else 0) + 1}
+
+    @classmethod
+    def failed(cls, device_index: int, budget_gib: float = 0.0):
+        """The remembered failure that makes a walk with `budget_gib` pointless on this device, or None."""
+        if not cls.enabled():
+            return None
+        with cls._lock:
+            v = cls._failed.get(device_identity(device_index))
+            # (a budget within one 8 GiB spacer of the failed one reaches nothing the failed walk did not)
+            return dict(v) if v is not None and float(budget_gib) <= v["budget_gib"] + 8.0 else None
+
+    @classmethod
+    def clear(cls):
+        with cls._lock:
+            cls._failed.clear()
 
 
 class ParkedBuffers:

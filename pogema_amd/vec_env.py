@@ -147,6 +147,11 @@ class VecPogema:
         if not (placement_budget_gib is None or placement_budget_gib in ("all", "half") or
                 (isinstance(placement_budget_gib, (int, float)) and placement_budget_gib >= 0)):
             raise ValueError("placement_budget_gib must be None, 'half', 'all' or a number of GiB >= 0")
+        if isinstance(placement_budget_gib, (int, float)) and 0 < placement_budget_gib < 1.0:
+            # (a walk moves in 8 GiB spacers; a budget below one GiB used to be turned silently into the probe-only mode
+            # while placement["policy"] still said "explicit" -- ADVICE r4)
+            raise ValueError("placement_budget_gib between 0 and 1 GiB cannot hold a single spacer: pass 0 (never walk), "
+                             "None (probe only on a shared device) or >= 1")
         self.placement_budget_gib = placement_budget_gib
         self._zone_ptrs = set()   # data_ptr() of the observation buffers that come from a zone pool
         # float32 is the reference's observation dtype (gymnasium Box float32) and the default.  The same 0/1 planes in a
@@ -497,6 +502,9 @@ class VecPogema:
             return self._plain_obs_buffers(n, policy=why)
         if budget < 1.0:
             return self._probe_only_obs_buffers(n, why)
+        failed = self._walk_known_to_fail(budget)
+        if failed is not None:
+            return self._probe_only_obs_buffers(n, failed)
         with walk_lock(self.device_index, wait=explicit) as mine:
             if not mine:  # somebody else is walking this device right now: it is not ours alone
                 return self._probe_only_obs_buffers(n, f"probe only, nothing held: another process is walking device {self.device_index}")
@@ -505,6 +513,16 @@ class VecPogema:
             if self.placement is not None:
                 self.placement.setdefault("policy", why)
             return bufs
+
+    def _walk_known_to_fail(self, budget: float) -> Optional[str]:
+        """The policy text of the negative cache (buffers.WalkVerdicts): an earlier engine of this process walked this
+        device with at least this budget and found no second zone -> do not hold the memory again, probe only."""
+        from .buffers import WalkVerdicts
+        v = WalkVerdicts.failed(self.device_index, budget)
+        if v is None:
+            return None
+        return (f"probe only, nothing held: an earlier walk of this process over {v['budget_gib']:.0f} GiB "
+                f"({v['candidates']} candidates) found no second zone on device {self.device_index} (negative cache)")
 
     def _probe_only_obs_buffers(self, n: int, why: str):
         """The co-tenant-safe form of the placement (a shared or loaded device): exactly the n buffers the engine needs, built
@@ -518,8 +536,9 @@ class VecPogema:
         except _lib.PgxError as e:
             return self._plain_obs_buffers(n, fallback=str(e), policy=why)
         if not pool.info["spread"]:
+            probe = {k: pool.info[k] for k in ("same_zone_us", "final_us")}  # what a bare store stream does on this box
             del pool
-            return self._plain_obs_buffers(n, policy=why + " -- the allocator does not stand between two zones")
+            return self._plain_obs_buffers(n, policy=why + " -- the allocator does not stand between two zones", probe=probe)
         self.placement = dict(pool.info, method="pgx_buffers (two HBM zones per buffer)", pools_tried=1, policy=why,
                               chosen=["zone"] * n)
         bufs = list(pool.tensors)
@@ -534,10 +553,12 @@ class VecPogema:
         # into each of them and into a few buffers as torch's allocator hands them out, keep the fastest n and give
         # the rest back.
         spare = self.SPARE_BUFFERS if self._has_state() else 0
+        from .buffers import WalkVerdicts
         try:
             pools = [self._zone_pool(n + spare)]
         except _lib.PgxError as e:  # e.g. a concurrent allocation took the memory during the walk: plain buffers
             return self._plain_obs_buffers(n, fallback=str(e))
+        WalkVerdicts.note_walk(self.device_index, pools[0].info, getattr(self, "_budget_now", 0.0))
         # candidates: (observation pass [us], order, kind, tensor, pool index, index inside the pool)
         cands = [(self._time_observe(t), i, "zone", t, 0, i) for i, t in enumerate(pools[0].tensors)]
         # The probe's promise, scaled to this tensor: if the n-th best buffer misses it by 10 % the fast stretch was
@@ -598,7 +619,8 @@ class VecPogema:
         return ZoneBuffers(self.obs_shape, self.obs_dtype, self.device, count=count, max_spacer_gib=budget, skip_gib=skip_gib,
                            sync_device=budget >= 1.0)  # (probe-only budgets: no device-wide synchronisation either)
 
-    def _plain_obs_buffers(self, n: int, fallback: Optional[str] = None, policy: Optional[str] = None):
+    def _plain_obs_buffers(self, n: int, fallback: Optional[str] = None, policy: Optional[str] = None,
+                           probe: Optional[dict] = None):
         """Observation buffers as torch's allocator hands them out (small tensors, probe switched off, no walk on a shared
         device, failed walk)."""
         if policy is None:
@@ -606,6 +628,8 @@ class VecPogema:
                       else "no walk: observation tensor below 128 MiB or placement_probe off")
         self.placement = {"spread": False, "method": "torch allocator", "candidates": 0, "budget_gib": 0.0, "policy": policy}
         self._zone_ptrs = set()
+        if probe:
+            self.placement.update(probe)
         if fallback is not None:
             self.placement["fallback"] = fallback
             torch.cuda.empty_cache()
@@ -876,21 +900,29 @@ class VecPogema:
 
     def _build_rollout_ring(self, slots: int, obs_bytes: int):
         """(pool, ring view) of `slots` zone-spread observation slots for rollout(), or None (no walk under the policy of
-        `placement_budget_gib`, or a failed one).  Two buffers more than needed are built; the run of `slots` consecutive
-        ones into which the observation stream itself is fastest becomes the ring, the others are given back."""
-        from .buffers import walk_lock
+        `placement_budget_gib`, or a failed one).  With a walk, two buffers more than needed are built; the run of `slots`
+        consecutive ones into which the observation stream itself is fastest becomes the ring, the others are given back.
+        Probe only (shared or loaded device, a busy walk lock, a walk this process has already seen fail): exactly `slots`
+        buffers where the allocator stands, no timing pass, no drops, nothing held -- as `_probe_only_obs_buffers`."""
+        from .buffers import WalkVerdicts, walk_lock
         budget, why, explicit = self._walk_policy()
         if budget <= 0.0:
             if self.placement is None:
                 self.placement = {"spread": False, "method": "torch allocator", "candidates": 0, "budget_gib": 0.0, "policy": why}
             return None
-        with walk_lock(self.device_index, wait=explicit and budget >= 1.0) as mine:
-            if not mine and budget >= 1.0:
-                return None
+        if budget >= 1.0:
+            failed = self._walk_known_to_fail(budget)
+            if failed is not None:
+                budget, why = self.PROBE_ONLY_GIB, failed
+        if budget < 1.0:
+            return self._probe_only_ring(slots, why)
+        with walk_lock(self.device_index, wait=explicit) as mine:
+            if not mine:
+                return self._probe_only_ring(slots, f"probe only, nothing held: another process is walking device {self.device_index}")
             self._budget_now = budget
             retry = float(os.environ.get("PGX_POOL_RETRY", "1.10"))
             pool, times, start, skip = None, None, 0, 0.0
-            for _ in range(3):  # as in _pick_obs_buffers: try further on while the ring misses the probe's promise
+            for attempt in range(3):  # as in _pick_obs_buffers: try further on while the ring misses the probe's promise
                 try:
                     cand = self._zone_pool(slots + 2, skip_gib=skip)
                 except _lib.PgxError as e:  # failed walk (memory taken meanwhile): keep an earlier pool, if any
@@ -898,19 +930,14 @@ class VecPogema:
                         self.placement = {"spread": False, "method": "torch allocator", "candidates": 0,
                                           "budget_gib": round(budget, 1), "policy": why, "fallback": str(e)}
                     break
+                if attempt == 0:
+                    WalkVerdicts.note_walk(self.device_index, cand.info, budget)
                 ct = [self._time_observe(t) for t in cand.tensors]
                 cs = min(range(3), key=lambda s: (max(ct[s:s + slots]), s))
                 if pool is None or max(ct[cs:cs + slots]) < max(times[start:start + slots]):
                     pool, times, start = cand, ct, cs
                 info = cand.info
                 del cand
-                if budget < 1.0 and not info["spread"]:  # probe only, and the allocator does not stand between two zones
-                    del pool
-                    self.placement = {"spread": False, "method": "torch allocator", "candidates": 0, "budget_gib": 0.0,
-                                      "policy": why + " -- the allocator does not stand between two zones"}
-                    return None
-                if budget < 1.0:
-                    break
                 if (not info["spread"] or info["final_us"] <= 0 or
                         max(times[start:start + slots]) <= retry * info["final_us"] * obs_bytes / (2 * (384 << 20))):
                     break
@@ -927,6 +954,23 @@ class VecPogema:
             if "xcd_shares" not in self.placement and self._bufs is None:
                 self.placement.update(self.tune_xcd_shares(ring[0], ring[1] if slots > 1 else None))
             return pool, ring
+
+    def _probe_only_ring(self, slots: int, why: str):
+        from .buffers import ZoneBuffers
+        plain = {"spread": False, "method": "torch allocator", "candidates": 0, "budget_gib": 0.0, "policy": why}
+        try:
+            pool = ZoneBuffers(self.obs_shape, self.obs_dtype, self.device, count=slots, max_spacer_gib=self.PROBE_ONLY_GIB,
+                               sync_device=False)
+        except _lib.PgxError as e:
+            self.placement = dict(plain, fallback=str(e))
+            return None
+        if not pool.info["spread"]:
+            self.placement = dict(plain, policy=why + " -- the allocator does not stand between two zones",
+                                  same_zone_us=pool.info["same_zone_us"], final_us=pool.info["final_us"])
+            del pool
+            return None
+        self.placement = dict(pool.info, method="pgx_buffers (two HBM zones per buffer)", policy=why)
+        return pool, pool.ring_view(0, slots)
 
     def set_targets(self, targets_xy, mask=None):
         """Overwrite current targets (int [batch, agents, 2], unpadded (row, col)) of the agents flagged in `mask`

@@ -73,3 +73,108 @@ def test_two_rank_sharded_rollout_equals_unsharded(tmp_path):
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok").exists()
+
+
+def _gather_worker(rank, world, port, tmpdir, shared):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pogema_amd.sharding import HostGather, gather_to_host, shard_bounds
+        GB, A = 11, 5  # ragged: 6 + 5 rows
+        start, count = shard_bounds(GB, world, rank)
+        fields = {"rewards": ((A,), torch.float32), "terminated": ((A,), torch.bool), "truncated": ((A,), torch.bool),
+                  "is_active": ((A,), torch.bool), "episode_done": ((), torch.bool), "metrics": ((6,), torch.float32),
+                  "obs": ((A, 3, 3, 3), torch.float32)}
+        g = HostGather(fields, GB, slots=2, shared=shared)
+        assert g.mode == ("shared segment" if shared else "private staging + gloo gather")
+        assert not os.path.exists("/dev/shm") or not [n for n in os.listdir("/dev/shm") if n.startswith("pgx_gather_")], \
+            "the segment's name must be gone once everybody has mapped it"
+        gen = torch.Generator().manual_seed(5)
+        history = []
+        for t in range(5):
+            full = {"rewards": torch.rand((GB, A), generator=gen), "terminated": torch.rand((GB, A), generator=gen) > 0.5,
+                    "truncated": torch.rand((GB, A), generator=gen) > 0.5, "is_active": torch.rand((GB, A), generator=gen) > 0.5,
+                    "episode_done": torch.rand((GB,), generator=gen) > 0.5, "metrics": torch.rand((GB, 6), generator=gen),
+                    "obs": torch.rand((GB, A, 3, 3, 3), generator=gen)}
+            # the engine's recycled outputs: rewards | terminated | truncated | is_active carved from ONE block
+            n = count * A
+            block = torch.empty(7 * n + 16, dtype=torch.uint8)
+            mine = {"rewards": block[:4 * n].view(torch.float32).view(count, A),
+                    "terminated": block[4 * n:5 * n].view(torch.bool).view(count, A),
+                    "truncated": block[5 * n:6 * n].view(torch.bool).view(count, A),
+                    "is_active": block[6 * n:7 * n].view(torch.bool).view(count, A)}
+            for k in mine:
+                mine[k].copy_(full[k][start:start + count])
+            for k in ("episode_done", "metrics", "obs"):
+                mine[k] = full[k][start:start + count].contiguous()
+            history.append(full)
+            ticket = g.start(**mine)
+            # one rank: the four carved outputs are one copy; several ranks: rows of other ranks lie in between
+            assert g.copies_per_step == 7
+            if t >= 1:  # pipelined: finish the previous step while this one is "in flight"
+                got = g.finish(ticket - 1)
+                if rank == 0:
+                    for k, want in history[t - 1].items():
+                        assert got[k].dtype == want.dtype and torch.equal(got[k], want), f"step {t - 1} field {k}"
+                else:
+                    assert got is None
+        got = g.finish()
+        if rank == 0:
+            for k, want in history[-1].items():
+                assert torch.equal(got[k], want)
+        # the same bytes as the plain gather_to_host
+        ref = gather_to_host(history[-1]["rewards"][start:start + count], GB)
+        if rank == 0:
+            assert torch.equal(ref, got["rewards"])
+            with pytest.raises(ValueError):
+                g.finish(0)  # long overwritten
+            open(os.path.join(tmpdir, f"ok{int(shared)}"), "w").write("ok")
+        g.close()
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shared", [True, False])
+def test_host_gather_two_ranks(tmp_path, shared):
+    """HostGather over gloo, world 2, ragged slices: every rank's rows land in place in rank 0's global tensors -- through
+    the shared segment (no collective on the data path) and through the private-staging + gloo fallback; pipelined
+    finish(ticket - 1); the segment leaves no name behind in /dev/shm."""
+    port = 29500 + ((os.getpid() + 7 + int(shared)) % 2000)
+    mp.spawn(_gather_worker, args=(2, port, str(tmp_path), shared), nprocs=2, join=True)
+    assert (tmp_path / f"ok{int(shared)}").exists()
+
+
+def test_host_gather_single_process_merges_adjacent_fields():
+    """One rank (no process group): fields that lie back to back in the source storage and in the slot travel as ONE copy
+    (the recycled output block: 7 bytes per agent), stragglers on their own; slots rotate; a stale ticket is refused."""
+    from pogema_amd.sharding import HostGather
+    B, A = 6, 4
+    n = B * A
+    fields = {"rewards": ((A,), torch.float32), "terminated": ((A,), torch.bool), "truncated": ((A,), torch.bool),
+              "is_active": ((A,), torch.bool), "episode_done": ((), torch.bool), "metrics": ((6,), torch.float32)}
+    g = HostGather(fields, B, slots=2)
+    assert g.mode == "private staging" and g.world == 1
+    outs = []
+    for t in range(3):
+        block = torch.randint(0, 2, (7 * n + 16,), dtype=torch.uint8)
+        mine = {"rewards": block[:4 * n].view(torch.float32).view(B, A), "terminated": block[4 * n:5 * n].view(torch.bool).view(B, A),
+                "truncated": block[5 * n:6 * n].view(torch.bool).view(B, A), "is_active": block[6 * n:7 * n].view(torch.bool).view(B, A),
+                "episode_done": torch.rand(B) > 0.5, "metrics": torch.rand(B, 6)}
+        tk = g.start(**mine)
+        assert g.copies_per_step == 3  # block, episode_done, metrics
+        got = g.finish(tk)
+        for k in fields:
+            assert torch.equal(got[k], mine[k])
+        outs.append((tk, {k: v.clone() for k, v in mine.items()}, got))
+    # slot of step 0 was rewritten by step 2; step 1's views are still intact
+    assert torch.equal(outs[1][2]["metrics"], outs[1][1]["metrics"])
+    assert torch.equal(outs[0][2]["metrics"], outs[2][1]["metrics"])
+    with pytest.raises(ValueError):
+        g.finish(0)
+    with pytest.raises(ValueError):
+        g.start(rewards=mine["rewards"])
+    with pytest.raises(ValueError):
+        g.start(**dict(mine, metrics=torch.rand(B, 5)))
+    g.close()

@@ -261,6 +261,90 @@ def launch_ranks(n: int, argv, stub: bool = False) -> int:
 
 
 # ----------------------------------------------------------------------------------------------------------
+# process groups: gloo is the default group (host side: agreement, per-rank records, HostGather); RCCL carries the clock
+# ----------------------------------------------------------------------------------------------------------
+def setup_groups(rank, world, device, try_rccl, fake_fail_ranks=()):
+    """-> (clock_group or None = the default gloo group, comm_device, label).
+
+    The default process group is ALWAYS gloo: it comes up wherever TCP to 127.0.0.1 works, and every decision that all
+    ranks must take together is taken on it.  With `try_rccl` an RCCL group over all ranks is created on top and exercised
+    once (all_reduce on a device tensor); whether it is USED is agreed collectively (all_reduce MIN of the per-rank
+    verdicts over gloo), so the ranks can never end up on mixed backends and nothing is re-initialised on the
+    same port.  A rank that hangs inside RCCL's bootstrap while another one has already failed is ended by a watchdog
+    after PGX_BENCH_GROUP_TIMEOUT seconds (default 300) with a non-zero exit code -- loud and bounded instead of the
+    launcher's 1800 s."""
+    import datetime
+    import threading
+    import torch
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in os.environ:  # PGX_BENCH_FORCE_DIST without a launcher
+        os.environ.update(MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
+    limit = float(os.environ.get("PGX_BENCH_GROUP_TIMEOUT", "300"))
+
+    def give_up():
+        print(f"bench.py: rank {rank} did not get its process groups up within {limit:.0f} s; exiting", file=sys.stderr, flush=True)
+        os._exit(75)
+
+    dog = threading.Timer(limit, give_up)
+    dog.daemon = True
+    dog.start()
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        if not try_rccl:
+            return None, torch.device("cpu"), "gloo"
+        group, ok, why = None, 1, ""
+        try:
+            if rank in fake_fail_ranks:
+                raise RuntimeError("PGX_BENCH_FAKE_RCCL_FAIL (test hook)")
+            group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=min(limit, 120.0)),
+                                   device_id=device if device.type == "cuda" else None)
+            t = torch.ones(1, device=device)
+            dist.all_reduce(t, group=group)
+            if device.type == "cuda":
+                torch.cuda.synchronize(device)
+            if int(t.item()) != world:
+                raise RuntimeError(f"RCCL all_reduce returned {t.item()} for {world} ranks")
+        except Exception as exc:  # noqa: BLE001
+            ok, why = 0, repr(exc)
+            print(f"bench.py: RCCL is not usable on rank {rank} ({why})", file=sys.stderr, flush=True)
+        verdict = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(verdict, op=dist.ReduceOp.MIN)  # gloo: the collective decision
+        if int(verdict.item()) == 1:
+            return group, device, "nccl"
+        reasons = [None] * world
+        dist.all_gather_object(reasons, why)
+        first = next((f"rank {r}: {w}" for r, w in enumerate(reasons) if w), "unknown")
+        return None, torch.device("cpu"), f"gloo (RCCL unusable on {sum(1 for w in reasons if w)} of {world} ranks; {first})"
+    finally:
+        dog.cancel()
+
+
+def _walks_in_process():
+    """Full-budget zone walks this process has run, over all its engines (a failed one is paid once: negative cache)."""
+    from pogema_amd.buffers import WalkVerdicts
+    return WalkVerdicts.walks
+
+
+def gpu_identity(dev_index):
+    """What tells this rank's GPU apart from its neighbours in the line: HIP uuid (= the unique_id of sysfs / KFD) and
+    PCI address."""
+    import torch
+    out = {"uuid": None, "pci": None, "name": None, "total_gib": None}
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+        out.update(name=pr.name, total_gib=round(pr.total_memory / float(1 << 30), 1))
+        u = getattr(pr, "uuid", None)
+        out["uuid"] = str(u) if u is not None else None
+        if hasattr(pr, "pci_bus_id"):
+            out["pci"] = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{getattr(pr, 'pci_device_id', 0):02x}"
+    except Exception:  # noqa: BLE001
+        pass
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------
 # the step under test
 # ----------------------------------------------------------------------------------------------------------
 def workload_grid_config(args, size, agents, r):
@@ -403,6 +487,82 @@ class EngineStep:
         pl = getattr(self.env, "placement", None) or {}
         us = pl.get("final_us") or 0.0
         return (2 * (384 << 20) / (us * 1e-6) / 1e9) if us > 0 else None
+
+    def measure_host_gather(self, steps, global_batch, windows=3, with_dist=False):
+        """Secondary figure: the host-side gather (north_star "host-side gather only") riding on the step loop.  Every
+        step's small outputs -- rewards f32, terminated / truncated / is_active (7 bytes per agent), episode_done and the
+        six episode metrics per env -- go to the host through pogema_amd.sharding.HostGather (page-locked segment, async
+        D2H on a side stream, finish() of step t-1 while step t runs), against the same loop without it.  Plus the raw
+        D2H leg: one observation tensor copied to pinned host memory, GB/s against PCIe Gen5 x16 (63 GB/s spec).
+        Collective when `with_dist` (every rank calls it; the shared segment is mapped by all of them)."""
+        import torch.distributed as dist
+        from pogema_amd.sharding import HostGather, start_step_gather, step_output_fields
+        torch, env = self.torch, self.env
+
+        def sync_all():
+            torch.cuda.synchronize()
+            if with_dist:
+                dist.barrier()
+
+        def plain(n):
+            for _ in range(n):
+                self.env.step(self.pool[self.i % len(self.pool)])
+                self.i += 1
+
+        gather = HostGather(step_output_fields(env), global_batch, device=env.device)
+        fields_bytes = sum(row for _, row in gather._layout.values()) * gather.count
+        checked = {}
+
+        def gathered(n):
+            prev = None
+            for _ in range(n):
+                out = self.env.step(self.pool[self.i % len(self.pool)])
+                self.i += 1
+                ticket = start_step_gather(gather, out)
+                del out
+                if prev is not None:
+                    host = gather.finish(prev)
+                    if host is not None and not checked:
+                        checked["rewards_sum"] = float(host["rewards"].sum())
+                prev = ticket
+            gather.finish(prev)
+
+        res = {}
+        for name, fn in (("loop_ms_per_step", plain), ("with_gather_ms_per_step", gathered)):
+            fn(max(8, steps // 10))
+            out = []
+            for _ in range(windows):
+                sync_all()
+                t0 = time.perf_counter()
+                fn(steps)
+                sync_all()
+                out.append((time.perf_counter() - t0) / steps * 1e3)
+            res[name] = statistics.median(out)
+        res.update(mode=gather.mode, copies_per_step=gather.copies_per_step, bytes_per_step_per_rank=fields_bytes,
+                   cost_us_per_step=round((res["with_gather_ms_per_step"] - res["loop_ms_per_step"]) * 1e3, 2),
+                   small_output_gbs=fields_bytes / (res["with_gather_ms_per_step"] * 1e-3) / 1e9)
+        gather.close()
+        # the D2H leg on its own: one whole observation tensor into pinned host memory
+        obs = env.observe(out=torch.empty(env.obs_shape, dtype=env.obs_dtype, device=env.device))
+        nbytes = obs.numel() * obs.element_size()
+        if nbytes <= (4 << 30):
+            host = torch.empty(obs.shape, dtype=obs.dtype, pin_memory=True)
+            side = torch.cuda.Stream(device=env.device)
+            torch.cuda.synchronize()
+            with torch.cuda.stream(side):
+                host.copy_(obs, non_blocking=True)
+                side.synchronize()
+                reps = max(2, min(8, int((2 << 30) // nbytes)))
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    host.copy_(obs, non_blocking=True)
+                side.synchronize()
+                dt = time.perf_counter() - t0
+            res.update(obs_d2h_gbs=nbytes * reps / dt / 1e9, obs_d2h_ms=dt / reps * 1e3, obs_bytes=nbytes, pcie_spec_gbs=63.0,
+                       obs_d2h_frac_of_pcie=nbytes * reps / dt / 1e9 / 63.0,
+                       obs_d2h_equal=bool(torch.equal(host, obs.cpu())))
+            del host
+        return res
 
     def close(self):
         self.env.close()
@@ -555,6 +715,7 @@ def make_parser():
                     help="skip the secondary figures (two pipelined engines; K-step rollout launches)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)  # tests only, see StubStep
+    ap.add_argument("--stub-rccl", action="store_true", help=argparse.SUPPRESS)  # tests only: attempt RCCL in stub mode
     return ap
 
 
@@ -576,16 +737,19 @@ def main(argv=None):
             raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; they must agree")
 
     fingerprint = box_fingerprint() if rank == 0 else None  # plain sysfs reads, before anything touches the GPU
-    group_note = None
 
     import torch
     import torch.distributed as dist
 
+    fake_fail = tuple(int(x) for x in os.environ.get("PGX_BENCH_FAKE_RCCL_FAIL", "").split(",") if x.strip())
+    force_dist = os.environ.get("PGX_BENCH_FORCE_DIST", "0") not in ("", "0")
+    clock_group, comm_device, group_label, rehearsal, dev_index = None, torch.device("cpu"), None, False, None
     if args.stub:
         device = torch.device("cpu")
-        if world > 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        if world > 1 or force_dist:
+            # (--stub-rccl: tests/test_bench_launch.py drives the RCCL attempt and the collective fallback on a box
+            # without any GPU -- RCCL fails on every rank there, or on the faked ones first)
+            clock_group, comm_device, group_label = setup_groups(rank, world, device, args.stub_rccl, fake_fail)
     else:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a HIP device; there is no CPU fallback for the product path")
@@ -595,26 +759,10 @@ def main(argv=None):
         dev_index = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(dev_index)
         device = torch.device("cuda", dev_index)
-        if world > 1 or os.environ.get("PGX_BENCH_FORCE_DIST", "0") not in ("", "0"):
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            if rehearsal:  # RCCL refuses two ranks on one device: gloo, host tensors (comm_device)
-                dist.init_process_group("gloo", rank=rank, world_size=world)
-            else:
-                if "MASTER_PORT" not in os.environ:  # PGX_BENCH_FORCE_DIST without a launcher
-                    os.environ.update(MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
-                try:
-                    dist.init_process_group("nccl", device_id=device)
-                except Exception as exc:  # noqa: BLE001
-                    # RCCL carries nothing but the clock (two 8-byte collectives per window): if it cannot be brought up
-                    # on this box the run is still a measurement -- gloo with host tensors, and the line says so
-                    print(f"bench.py: RCCL init failed on rank {rank} ({exc!r}); using gloo for the barriers and the clock",
-                          file=sys.stderr)
-                    group_note = f"gloo (RCCL init failed: {exc!r})"
-                    dist.init_process_group("gloo", rank=rank, world_size=world)
+        if world > 1 or force_dist:
+            # rehearsal: RCCL refuses two ranks on one device -> gloo only, host tensors for the clock
+            clock_group, comm_device, group_label = setup_groups(rank, world, device, not rehearsal, fake_fail)
     use_dist = dist.is_initialized()
-    rehearsal = (not args.stub) and share_device() and world > torch.cuda.device_count()
-    # where the clock / kernel-time tensors live: on the device for RCCL, on the host for gloo
-    comm_device = torch.device("cpu") if (args.stub or rehearsal or (use_dist and dist.get_backend() == "gloo")) else device
 
     from pogema_amd.sharding import shard_bounds
     per_gpu, size, agents, r = WORKLOADS[args.workload]
@@ -634,14 +782,14 @@ def main(argv=None):
     def barrier():
         sync()
         if use_dist:
-            dist.barrier()
+            dist.barrier(group=clock_group)
         sync()
 
     def reduce_max(x: float) -> float:
         if not use_dist:
             return x
         t = torch.tensor([x], dtype=torch.float64, device=comm_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=clock_group)
         return float(t.item())
 
     def timed_windows(step, n_windows):
@@ -675,8 +823,27 @@ def main(argv=None):
     if use_dist:
         t = torch.tensor([kernel_ms], dtype=torch.float64, device=comm_device)
         parts = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(parts, t)
+        dist.all_gather(parts, t, group=clock_group)
         per_rank_kernel = [float(p.item()) for p in parts]
+
+    # every rank's own record: which GPU, where its buffers lie, what a bare store stream does there --
+    # with max-over-ranks timing ONE slow GPU sets the node's clock, and the line must say which one and why
+    abytes = {"int8": 1, "int32": 4, "int64": 8}[args.action_dtype]
+    bpas = algorithmic_bytes_per_agent_step(size, agents, r, OBS_BYTES[args.obs_dtype], abytes)
+    my = {"rank": rank, "envs": batch, "kernel_ms": kernel_ms, "host": socket.gethostname()}
+    if not args.stub:
+        pf = step.placement_fields()
+        my_gbs = bpas * batch * agents / (kernel_ms * 1e-3) / 1e9
+        box_gbs = step.box_store_stream_gbs()
+        my.update(device=dev_index, gpu=gpu_identity(dev_index), achieved_gbs=my_gbs, frac=my_gbs / HBM_PEAK_GBS,
+                  spread=pf["spread"], walk_candidates=pf["walk_candidates"], spacer_gib_held=pf["spacer_gib_held"],
+                  probe_same_zone_us=pf["probe_same_zone_us"], probe_as_placed_us=pf["probe_as_placed_us"],
+                  box_store_stream_gbs=box_gbs, frac_of_box_store_stream=(my_gbs / box_gbs) if box_gbs else None,
+                  chosen=pf["chosen"], policy=pf["policy"], fallback=pf["fallback"])
+    per_rank = [my]
+    if use_dist:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, my)  # the default group: gloo, host side
 
     # the same workload into buffers as torch's allocator hands them out (no zone placement), AFTER the main measurement:
     # allocating and freeing them first would leave holes that the zone walk of the main run falls into
@@ -744,14 +911,24 @@ def main(argv=None):
             except Exception as exc:  # noqa: BLE001
                 extra_errors["graph"] = repr(exc)
             torch.cuda.empty_cache()
+        try:
+            extras["host_gather"] = step.measure_host_gather(min(n, 400), total_envs)
+        except Exception as exc:  # noqa: BLE001
+            extra_errors["host_gather"] = repr(exc)
         if extra_errors:
             extras["errors"] = extra_errors
+    elif not args.stub and not args.no_extras and world > 1 and args.graph <= 0 and not args.no_obs:
+        # N > 1: the gather is the one cross-rank piece of the product path -- every rank takes part (shared segment,
+        # gloo barrier per step); a failure on any rank must not cost the line, so the verdict is agreed first
+        try:
+            hg = step.measure_host_gather(min(args.steps, 200), total_envs, with_dist=True)
+        except Exception as exc:  # noqa: BLE001
+            hg = {"error": repr(exc)}
+        extras["host_gather"] = hg
 
     if rank == 0:
         n_agent_steps = total_envs * agents * args.steps
         value = n_agent_steps / elapsed
-        abytes = {"int8": 1, "int32": 4, "int64": 8}[args.action_dtype]
-        bpas = algorithmic_bytes_per_agent_step(size, agents, r, OBS_BYTES[args.obs_dtype], abytes)
         alg_bytes = bpas * batch * agents  # per launch (this GPU's shard)
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None
@@ -797,7 +974,7 @@ def main(argv=None):
                                                                 ("soft_vertex", "soft_occupancy", "coop_reward", "bad_action",
                                                                  "lifelong_rng", "generator_rng")},
                        "rehearsal": bool(rehearsal),
-                       "process_group": (group_note or dist.get_backend()) if use_dist else None,
+                       "process_group": group_label if use_dist else None,
                        "launch": f"hipGraph of {args.graph} steps" if args.graph > 0 else "one pgx_step launch per step",
                        "obs_buffers": step.describe_buffers()},
             "roofline": {"bound": "hbm" if (args.buffers != 1 or alg_bytes > (200 << 20)) else "hbm (output tensor rewritten in place: largely Infinity-Cache resident)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -815,6 +992,12 @@ def main(argv=None):
                          "kernel_ms_windows": kernel,
                          "default_placement_kernel_ms": default_ms,
                          "box_store_stream_gbs": None if args.stub else step.box_store_stream_gbs(),
+                         # kernel quality separated from the box: the step against the bare store stream timed on the
+                         # same GPU, same placement (1.0 = the kernel IS the box's write ceiling)
+                         "frac_of_box_store_stream": per_rank[0].get("frac_of_box_store_stream"),
+                         "per_rank": per_rank,
+                         "slowest_rank": max(range(len(per_rank)), key=lambda i: per_rank[i]["kernel_ms"]),
+                         "zone_walks_in_process": None if args.stub else _walks_in_process(),
                          "algorithmic_bytes_per_agent_step": bpas, "algorithmic_bytes_per_launch": alg_bytes,
                          "profile_command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-default-placement "
                                             "--no-cpu-baseline --no-extras  (the default-placement window and the secondary "
@@ -842,6 +1025,13 @@ def main(argv=None):
                      what="the same pgx_step launches, 32 consecutive steps captured in one HIP graph (two alternating output "
                           "sets, 32 different action tensors) and replayed: what the GPU needs per step when no host work "
                           "lies between two launches; `value` minus this is the host-bound part of a Python step() loop")
+        if "host_gather" in extras and "error" not in extras["host_gather"]:
+            e = extras["host_gather"]
+            e.update(what="the step loop with the host-side gather riding on it (pogema_amd.sharding.HostGather: every step's "
+                          "rewards / terminated / truncated / is_active / episode_done / metrics into one page-locked host "
+                          "segment by async D2H on a side stream, finish(t-1) while step t runs; N > 1: all ranks DMA into one "
+                          "shared segment, one gloo barrier per step, no collective on the data path) against the same loop "
+                          "without it; obs_d2h_*: one observation tensor to pinned host memory, against PCIe Gen5 x16")
         if "held_pair" in extras:
             e = extras["held_pair"]
             e.update(value=batch * agents / (e["ms_per_step"] * 1e-3), unit="agent-steps/s",

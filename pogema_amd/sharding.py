@@ -134,6 +134,8 @@ class HostGather:
             self.mode = "private staging" + (" + gloo gather" if self.world > 1 else "")
         self._stream = torch.cuda.Stream(device=self._device) if self._cuda else None
         self._events = [None] * self.slots
+        self._inflight = [None] * self.slots  # source tensors of a slot's copies, referenced until finish() / slot reuse:
+        #                                       a recycling producer (reuse_buffers='recycle') must not hand them out again
         self._seq = 0
         self._done = -1
         self.copies_per_step = None  # statistics: D2H copies the last start() issued (after merging)
@@ -267,8 +269,10 @@ class HostGather:
                 done.record(self._stream)
             for _, _, t, _ in merged:
                 t.record_stream(self._stream)    # torch's allocator: the side stream still reads it
+            if prev is not None:
+                prev.synchronize()               # (slot reuse without finish(): its old sources are released below)
             self._events[slot] = done
-            del prev
+            self._inflight[slot] = tuple(tensors.values())
         else:
             for hoff, nbytes, t, _ in merged:
                 self._host[hoff:hoff + nbytes].copy_(self._bytes_of(t, nbytes))
@@ -290,6 +294,7 @@ class HostGather:
         slot = ticket % self.slots
         if self._cuda and self._events[slot] is not None:
             self._events[slot].synchronize()
+        self._inflight[slot] = None
         if self.world > 1 and self.shared:
             dist.barrier(group=self._group)  # every rank's rows are in place (DMA complete + host-visible before it entered)
         if self.world > 1 and not self.shared:
@@ -323,6 +328,20 @@ class HostGather:
             return out
         dist.gather(packed, gather_list=None, dst=self.dst, group=self._group)
         return None
+
+
+def start_step_gather(gather: "HostGather", step_result, with_obs: bool = False) -> int:
+    """`gather.start` for the tuple `VecPogema.step` returned.  rewards / terminated / truncated / is_active (and obs) are
+    the caller's tensors; infos['episode_done'] and infos['metrics'] are ENGINE-owned and rewritten by the next step, so
+    they are snapshotted on the producer stream first (two tiny device copies) -- the D2H then cannot race the next step."""
+    obs, rewards, terminated, truncated, infos = step_result
+    t = {"rewards": rewards, "terminated": terminated, "truncated": truncated, "is_active": infos["is_active"]}
+    if "episode_done" in gather.fields:
+        t["episode_done"] = infos["episode_done"].clone()
+        t["metrics"] = infos["metrics"].clone()
+    if with_obs:
+        t["obs"] = obs
+    return gather.start(**t)
 
 
 def step_output_fields(env, with_obs: bool = False, with_metrics: bool = True) -> dict:

@@ -16,3 +16,13 @@ def pytest_configure(config):
 def engine_lib():
     from pogema_amd import _lib
     return _lib.load()
+
+
+@pytest.fixture(autouse=True)
+def _forget_walk_verdicts():
+    """The zone walk's negative cache is per process; tests that assert what a walk finds must not inherit an earlier
+    test's verdict."""
+    yield
+    mod = sys.modules.get("pogema_amd.buffers")
+    if mod is not None:
+        mod.WalkVerdicts.clear()

@@ -74,3 +74,37 @@ def test_under_torchrun_env_single_rank_stub():
                         "MASTER_PORT": str(_free_port())})
     assert p.returncode == 0, p.stderr
     assert json.loads(p.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def _stub_line(p):
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_per_rank_records_are_gathered():
+    """the line carries one record per rank (rank, envs, kernel time, host; on a GPU also which GPU, where its
+    buffers lie and what a bare store stream does there) and names the slowest rank -- the one that sets the node's clock."""
+    line = _stub_line(_run(["--gpus", "3", "--stub", "--steps", "10", "--warmup", "1", "--windows", "2", "--workload", "cfg3",
+                            "--global-batch", "10"]))
+    pr = line["roofline"]["per_rank"]
+    assert [e["rank"] for e in pr] == [0, 1, 2] and [e["envs"] for e in pr] == [4, 3, 3]
+    assert all(e["kernel_ms"] > 0 and e["host"] for e in pr)
+    assert [e["kernel_ms"] for e in pr] == pytest.approx(line["roofline"]["kernel_ms_per_rank"])
+    assert line["roofline"]["slowest_rank"] == 2  # rank r sleeps 0.5 ms * (r + 1) per step
+    assert line["config"]["process_group"] == "gloo"
+
+
+@pytest.mark.parametrize("fake", ["", "1"])
+def test_rccl_fallback_is_a_collective_decision(fake):
+    """whether RCCL or gloo carries the clock is decided by ALL ranks together (all_reduce MIN over the gloo
+    default group), never per rank inside an except block.  No GPU here, so RCCL fails -- on every rank, or (faked) on
+    rank 1 before rank 0 has even tried: both ways every rank ends up on gloo, the line says why, nobody hangs."""
+    p = _run(["--gpus", "2", "--stub", "--stub-rccl", "--steps", "5", "--warmup", "0", "--windows", "1"],
+             env_extra={"PGX_BENCH_FAKE_RCCL_FAIL": fake, "PGX_BENCH_GROUP_TIMEOUT": "120"}, timeout=280)
+    line = _stub_line(p)
+    label = line["config"]["process_group"]
+    assert label.startswith("gloo (RCCL unusable on ") and "of 2 ranks" in label
+    assert "RCCL is not usable on rank" in p.stderr
+    assert line["n_gpus"] == 2 and len(line["roofline"]["per_rank"]) == 2

@@ -17,6 +17,30 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
 QUICK = ["--steps", "40", "--warmup", "5", "--windows", "2", "--no-cpu-baseline", "--no-extras", "--no-default-placement"]
+WITH_GATHER = [a for a in QUICK if a != "--no-extras"]  # N > 1: the only secondary figure is the host-side gather
+
+
+def _check_per_rank(line, world):
+    """VERDICT r4 #1a: one self-explaining record per rank."""
+    pr = line["roofline"]["per_rank"]
+    assert [e["rank"] for e in pr] == list(range(world))
+    for e in pr:
+        assert e["kernel_ms"] > 0 and e["envs"] > 0 and 0 < e["frac"] < 1.0
+        assert e["gpu"]["uuid"] or e["gpu"]["pci"], "the record must say WHICH GPU"
+        assert isinstance(e["spread"], bool) and "walk_candidates" in e and "policy" in e
+        assert e["box_store_stream_gbs"] is None or e["box_store_stream_gbs"] > 1000
+        if e["box_store_stream_gbs"]:
+            assert e["frac_of_box_store_stream"] == pytest.approx(e["achieved_gbs"] / e["box_store_stream_gbs"])
+    assert [e["kernel_ms"] for e in pr] == pytest.approx(line["roofline"]["kernel_ms_per_rank"])
+    assert 0 <= line["roofline"]["slowest_rank"] < world
+
+
+def _check_host_gather(line, world):
+    hg = line["secondary"]["host_gather"]
+    assert "error" not in hg, hg
+    assert hg["mode"] == ("shared segment" if world > 1 else "private staging")
+    assert hg["with_gather_ms_per_step"] > 0 and hg["loop_ms_per_step"] > 0 and hg["bytes_per_step_per_rank"] > 0
+    assert hg["obs_d2h_equal"] is True and 5 < hg["obs_d2h_gbs"] < 70
 
 
 def _env(**extra):
@@ -49,9 +73,12 @@ def _check_two_rank_line(line, batch, agents):
 
 def test_self_launched_two_ranks_share_the_device():
     """`python bench.py --gpus 2` (bench.py starts the ranks itself), headline workload, both engines on cuda:0."""
-    p = subprocess.run([sys.executable, BENCH, "--gpus", "2"] + QUICK, capture_output=True, text=True, timeout=900,
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2"] + WITH_GATHER, capture_output=True, text=True, timeout=900,
                        env=_env(PGX_BENCH_SHARE_DEVICE="1"))
-    _check_two_rank_line(_line(p), 8192, 64)
+    line = _line(p)
+    _check_two_rank_line(line, 8192, 64)
+    _check_per_rank(line, 2)
+    _check_host_gather(line, 2)
 
 
 def test_torchrun_form_two_ranks_configs3_sharded():
@@ -85,17 +112,40 @@ def test_single_rank_through_rccl():
     assert line["metric"].startswith("agent-steps/sec (whole node), 64-agent 64x64 grid")
     assert len(line["roofline"]["kernel_ms_per_rank"]) == 1
     assert 0.3 < line["roofline"]["frac"] < 1.0
+    _check_per_rank(line, 1)
+    assert line["roofline"]["frac_of_box_store_stream"] == line["roofline"]["per_rank"][0]["frac_of_box_store_stream"]
 
 
 def test_eight_ranks_configs3_at_its_stated_size():
     """BASELINE configs[3] exactly as stated -- 65536 envs sharded over EIGHT ranks (strong scaling, shard_bounds) -- with
     eight real processes and engines, all on the one device of the box: the launch the driver's 8-GPU node will see, minus
     the seven other GPUs."""
-    p = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--workload", "cfg3", "--global-batch", "65536"] + QUICK,
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--workload", "cfg3", "--global-batch", "65536"] + WITH_GATHER,
                        capture_output=True, text=True, timeout=900, env=_env(PGX_BENCH_SHARE_DEVICE="1"))
     line = _line(p)
+    _check_per_rank(line, 8)
+    _check_host_gather(line, 8)
     assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["metric"].startswith("REHEARSAL (8 ranks share")
     assert line["config"]["global_batch"] == 65536 and line["config"]["envs_per_gpu"] == 8192
     per_rank = line["roofline"]["kernel_ms_per_rank"]
     assert len(per_rank) == 8 and all(k > 0 for k in per_rank)
     assert line["value"] == pytest.approx(65536 * 16 * 40 / (line["ms_per_step"] * 40 * 1e-3), rel=1e-6)
+
+
+def test_a_failed_walk_is_paid_once_by_the_whole_bench():
+    """VERDICT r4 #1b at the level of bench.py: on a GPU where the walk finds nothing (forced here: PGX_ZONE_SCAN accepts no
+    candidate) the headline engine walks ONCE; the secondary engines (two pipelined halves, the rollout ring) reuse the
+    verdict instead of holding the memory three more times."""
+    args = ["--steps", "40", "--warmup", "5", "--windows", "2", "--no-cpu-baseline"]
+    p = subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, timeout=900,
+                       env=_env(PGX_ZONE_SCAN="1", PGX_ZONE_SPACER_GIB="24"))
+    line = _line(p)
+    rf = line["roofline"]
+    assert rf["zone_walks_in_process"] == 1, rf["zone_walks_in_process"]
+    assert rf["placement"]["spread"] is False and rf["placement"]["walk_candidates"] == 3
+    assert rf["box_store_stream_gbs"] and rf["frac_of_box_store_stream"] == pytest.approx(rf["achieved"] / rf["box_store_stream_gbs"])
+    sec = line["secondary"]
+    assert "errors" not in sec, sec.get("errors")
+    assert {"pipelined", "rollout", "host_gather"} <= set(sec)
+    _check_host_gather(line, 1)
+    _check_per_rank(line, 1)

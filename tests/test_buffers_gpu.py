@@ -411,3 +411,115 @@ def test_walk_lock_names_the_physical_device():
     from pogema_amd.buffers import device_identity
     ident = device_identity(0)
     assert ident.startswith(("uuid_", "pci_")), f"no physical identity for device 0: {ident!r}"
+
+
+def test_a_failed_walk_is_paid_once_per_process(monkeypatch):
+    """VERDICT r4 #1b: once a full-budget walk has found no second zone on a device, later engines of the process -- of any
+    shape, also rollout rings -- go straight to the probe-only placement (nothing held) instead of holding the memory
+    again.  The failure is forced: PGX_ZONE_SCAN makes the walk run its whole budget and accept nothing."""
+    import torch
+    from pogema_amd import GridConfig, VecPogema, buffers, release_cached_buffers
+    monkeypatch.setenv("PGX_ZONE_SCAN", "1")
+    monkeypatch.setenv("PGX_ZONE_SPACER_GIB", "24")
+    release_cached_buffers()
+    w0 = buffers.WalkVerdicts.walks
+    probes = []
+    real_zone = buffers.ZoneBuffers.__init__
+
+    def spying_zone(self, shape, dtype, device, count=2, max_spacer_gib=None, skip_gib=0.0, sync_device=True):
+        probes.append((count, max_spacer_gib))
+        return real_zone(self, shape, dtype, device, count=count, max_spacer_gib=max_spacer_gib, skip_gib=skip_gib,
+                         sync_device=sync_device)
+
+    monkeypatch.setattr(buffers.ZoneBuffers, "__init__", spying_zone)
+    cfg = GridConfig(size=32, num_agents=32, obs_radius=5, density=0.3, seed=5)
+    a = VecPogema(cfg, batch=3000, auto_reset=True)
+    a.reset(seed=5)
+    assert buffers.WalkVerdicts.walks == w0 + 1 and not a.placement["spread"] and a.placement["candidates"] == 3
+    assert buffers.WalkVerdicts.failed(0, 24.0) is not None and buffers.WalkVerdicts.failed(0, 100.0) is None
+    n_walk_probes = len(probes)
+    assert probes[0][1] == 24.0
+    # another shape, same process: no walk, a probe-only pool of exactly the buffers it needs
+    b = VecPogema(cfg, batch=3300, auto_reset=True)
+    b.reset(seed=5)
+    assert buffers.WalkVerdicts.walks == w0 + 1, "the failed walk was repeated"
+    assert "negative cache" in b.placement["policy"] and b.placement["policy"].startswith("probe only, nothing held")
+    assert probes[n_walk_probes:] == [(2, VecPogema.PROBE_ONLY_GIB)]
+    assert b.placement.get("same_zone_us", 0) > 0, "the probe's timing must survive into the placement record (box_store_stream_gbs)"
+    # ... and a rollout ring of a third engine: exactly its slots, no timing pass
+    del probes[:]
+    c = VecPogema(cfg, batch=3100, auto_reset=True)
+    c.reset(seed=5)
+    acts = torch.randint(0, 5, (4, 3100, 32), device="cuda", dtype=torch.int8)
+    ref = VecPogema(cfg, batch=3100, auto_reset=True, reuse_buffers=False, placement_budget_gib=0)
+    ref.reset(seed=5)
+    out = c.rollout(acts, obs_slots=2)
+    want = [ref.step(acts[t])[0] for t in range(4)]
+    assert torch.equal(out["obs"][0], want[2]) and torch.equal(out["obs"][1], want[3])
+    assert buffers.WalkVerdicts.walks == w0 + 1 and all(p[1] == VecPogema.PROBE_ONLY_GIB for p in probes)
+    assert (2, VecPogema.PROBE_ONLY_GIB) in probes
+    # a larger explicit budget than the one that failed may walk again; forgetting the verdict re-enables the default
+    d = VecPogema(cfg, batch=3200, auto_reset=True, placement_budget_gib=48.0)
+    d.reset(seed=5)
+    assert buffers.WalkVerdicts.walks == w0 + 2 and d.placement["candidates"] == 6
+    release_cached_buffers()
+    assert buffers.WalkVerdicts.failed(0, 24.0) is None
+    monkeypatch.setenv("PGX_WALK_NEGATIVE_CACHE", "0")
+    buffers.WalkVerdicts.note_walk(0, {"spread": False, "candidates": 3}, 24.0)
+    assert buffers.WalkVerdicts.failed(0, 24.0) is None
+    for e in (a, b, c, d, ref):
+        e.close(release=True)
+
+
+def test_explicit_budget_below_one_spacer_is_refused():
+    """placement_budget_gib in (0, 1) used to become the probe-only mode silently while the policy text still
+    said 'explicit'."""
+    from pogema_amd import GridConfig, VecPogema
+    with pytest.raises(ValueError, match="cannot hold a single spacer"):
+        VecPogema(GridConfig(size=8, num_agents=2), batch=4, placement_budget_gib=0.5)
+
+
+def test_rollout_ring_probe_only_builds_exactly_its_slots(monkeypatch):
+    """on a shared / loaded device (or with a busy walk lock) the rollout ring is built like the step buffers:
+    exactly `slots` buffers, no timing pass, no drops (pgx_buffers_drop synchronises the device), nothing held."""
+    import torch
+    from pogema_amd import GridConfig, VecPogema, buffers
+    cfg = GridConfig(size=32, num_agents=32, obs_radius=5, density=0.3, seed=5)
+    B = 3000
+    real = torch.cuda.mem_get_info
+    total = real(0)[1]
+    probes, drops, timed = [], [], []
+    real_zone = buffers.ZoneBuffers.__init__
+
+    def spying_zone(self, shape, dtype, device, count=2, max_spacer_gib=None, skip_gib=0.0, sync_device=True):
+        probes.append((count, max_spacer_gib, sync_device))
+        return real_zone(self, shape, dtype, device, count=count, max_spacer_gib=max_spacer_gib, skip_gib=skip_gib,
+                         sync_device=sync_device)
+
+    monkeypatch.setattr(buffers.ZoneBuffers, "__init__", spying_zone)
+    monkeypatch.setattr(buffers.ZoneBuffers, "drop", lambda self, i: drops.append(i))
+    real_time = VecPogema._time_observe
+    monkeypatch.setattr(VecPogema, "_time_observe", lambda self, *a: (timed.append(1), real_time(self, *a))[1])
+    acts = torch.randint(0, 5, (3, B, 32), device="cuda", dtype=torch.int8)
+    ref = VecPogema(cfg, batch=B, auto_reset=True, reuse_buffers=False, placement_budget_gib=0)
+    ref.reset(seed=5)
+    want = [ref.step(acts[t])[0] for t in range(3)]
+    for case in ("loaded", "locked"):
+        del probes[:], drops[:], timed[:]
+        env = VecPogema(cfg, batch=B, auto_reset=True, reuse_buffers=False)
+        env.reset(seed=5)
+        if case == "loaded":
+            monkeypatch.setattr(torch.cuda, "mem_get_info", lambda *a: (int(0.6 * total), total))
+            out = env.rollout(acts, obs_slots=3)
+        else:
+            monkeypatch.setattr(torch.cuda, "mem_get_info", lambda *a: (int(0.97 * total), total))
+            with buffers.walk_lock(0) as held:
+                assert held
+                out = env.rollout(acts, obs_slots=3)
+        assert probes == [(3, VecPogema.PROBE_ONLY_GIB, False)] and not drops and not timed, (case, probes, drops, timed)
+        assert env.placement["policy"].startswith("probe only, nothing held")
+        for t in range(3):
+            assert torch.equal(out["obs"][t], want[t])
+        env.close(release=True)
+    monkeypatch.setattr(torch.cuda, "mem_get_info", real)
+    ref.close()

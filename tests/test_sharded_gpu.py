@@ -107,7 +107,8 @@ def _rank(rank, world, port, tmpdir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from pogema_amd import GridConfig, VecPogema
-        from pogema_amd.sharding import gather_to_host, make_sharded_env, shard_bounds
+        from pogema_amd.sharding import (HostGather, gather_to_host, make_sharded_env, shard_bounds, start_step_gather,
+                                         step_output_fields)
         from util import generate_instances, random_actions
         torch.cuda.set_device(0)  # both ranks share the one device of the box
         GB, size, A, r, T = 1001, 24, 12, 4, 14  # a global batch the world size does not divide
@@ -120,9 +121,37 @@ def _rank(rank, world, port, tmpdir):
         actions = torch.from_numpy(random_actions(T, GB, A, 3)).to(torch.int8)
         mine = actions[:, start:start + count].cuda()
         rew_sum = torch.zeros((count, A), device="cuda")
+        # the engineered gather rides on the loop: every step's outputs (observation included here) DMA'd into the shared
+        # page-locked segment by both ranks, finished one step late (pipelined) -- and the plain gather_to_host of the same
+        # tensors must return the same bytes
+        hg = HostGather(step_output_fields(env, with_obs=True), GB, slots=2)
+        assert hg.mode == "shared segment" and hg._host.is_pinned()
+        prev, per_step = None, []
         for t in range(T):
-            obs, rew, term, trunc, info = env.step(mine[t])
+            res = env.step(mine[t])
+            obs, rew, term, trunc, info = res
             rew_sum += rew
+            ticket = start_step_gather(hg, res, with_obs=True)
+            plain = {"rewards": gather_to_host(rew, GB), "terminated": gather_to_host(term, GB),
+                     "truncated": gather_to_host(trunc, GB), "is_active": gather_to_host(info["is_active"], GB),
+                     "episode_done": gather_to_host(info["episode_done"], GB), "metrics": gather_to_host(info["metrics"], GB),
+                     "obs": gather_to_host(obs, GB)}
+            per_step.append(plain)
+            if prev is not None:
+                got_prev = hg.finish(prev)
+                if rank == 0:
+                    for k, want in per_step[prev].items():
+                        assert got_prev[k].dtype == want.dtype and torch.equal(got_prev[k], want), f"HostGather step {prev}: {k}"
+                else:
+                    assert got_prev is None
+                per_step[prev] = None
+            prev = ticket
+        last = hg.finish(prev)
+        if rank == 0:
+            for k, want in per_step[prev].items():
+                assert torch.equal(last[k], want), f"HostGather last step: {k}"
+        del last
+        hg.close()
         st = env.get_state()
         got = {k: gather_to_host(v, GB) for k, v in (("obs0", obs0), ("obs", obs), ("rew_sum", rew_sum), ("trunc", trunc),
                                                      ("xy", st["agents_xy"]), ("tgt", st["targets_xy"]),

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PGX_ABI_VERSION 5
+#define PGX_ABI_VERSION 6
 
 /* error codes */
 #define PGX_OK 0
@@ -129,7 +129,10 @@ typedef struct pgx_config {
     int32_t bad_action;        /* PGX_BAD_ACTION_*  (0 = noop)                                           */
     int32_t lifelong_rng;      /* PGX_LIFELONG_RNG_* (0 = the build's counter-based stream)              */
     int32_t soft_occupancy;    /* PGX_SOFT_OCCUPANCY_* (0 = the literal index-order loop, recalled)      */
-    int32_t reserved0;         /* must be 0                                                              */
+    int32_t abi_version;       /* must be PGX_ABI_VERSION of the header the caller was COMPILED against: pgx_create   */
+                               /* refuses any other value, so a caller built against an older header fails loudly      */
+                               /* instead of getting renumbered semantics (ABI 5 swapped the two soft_occupancy        */
+                               /* values: 0 became the index-order loop).  ABI <= 5 had `reserved0 = 0` here.          */
 } pgx_config;
 
 typedef struct pgx_env pgx_env; /* opaque */
@@ -232,7 +235,8 @@ typedef struct pgx_geometry {
     int32_t multi_wave;     /* 1: one environment per workgroup of `waves` waves (num_agents > 64, or helper waves)  */
     int32_t p16;            /* 1: window side <= 16, packed 16-bit row masks                                         */
     int32_t stagger;        /* cohort stagger of the single-wave kernel (0 = off)                                    */
-    int32_t store_policy;   /* observation stores: 0 plain, 1 nontemporal, 2 sc1 write-through                       */
+    int32_t store_policy;   /* observation stores AS EXECUTED: 0 plain, 1 nontemporal, 2 sc1 write-through (the lighter */
+                            /* formats' generic funnels know 0 and 1 only: a chosen 2 runs -- and is reported -- as 0)  */
     int32_t state_stores;   /* when the small per-step result stores are issued: 0 at once, 1 after the LDS barrier, 2 after the stream */
     int32_t grid;           /* workgroups launched                                                                   */
     int32_t lds_bytes;      /* dynamic LDS per workgroup                                                             */

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PGX_LIB: diagnostic override (A/B of two builds of the SAME engine on one box); never a fallback
 LIB_PATH = os.environ.get("PGX_LIB") or os.path.join(_HERE, "libpogema_amd.so")
 
-PGX_ABI_VERSION = 5
+PGX_ABI_VERSION = 6
 
 COLLISION_SYSTEMS = {"priority": 0, "block_both": 1, "soft": 2}
 ON_TARGET = {"finish": 0, "restart": 1, "nothing": 2}
@@ -94,7 +94,7 @@ class PgxConfig(C.Structure):
         ("seed", C.c_uint64), ("env_index_base", C.c_int64),
         ("random_outside", C.c_int32), ("outside_density", C.c_float),
         ("soft_vertex_rule", C.c_int32), ("coop_reward", C.c_int32), ("bad_action", C.c_int32), ("lifelong_rng", C.c_int32),
-        ("soft_occupancy", C.c_int32), ("reserved0", C.c_int32),
+        ("soft_occupancy", C.c_int32), ("abi_version", C.c_int32),
     ]
 
 

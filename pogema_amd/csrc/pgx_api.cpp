@@ -137,6 +137,10 @@ static void apply_xcd_shares(pgx_env* e) {
 int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
     if (!cfg || !out) return fail(PGX_E_INVALID, "pgx_create: null argument");
     *out = nullptr;
+    if (cfg->abi_version != PGX_ABI_VERSION)
+        return fail(PGX_E_INVALID, "pgx_config.abi_version is %d but this library implements ABI %d: rebuild the caller against "
+                    "include/pogema_amd.h and set cfg.abi_version = PGX_ABI_VERSION (ABI 5 renumbered soft_occupancy: 0 is "
+                    "the index-order loop, 1 the exact set; ABI <= 5 callers pass 0 in this field)", cfg->abi_version, PGX_ABI_VERSION);
     if (cfg->batch < 1) return fail(PGX_E_INVALID, "batch must be >= 1 (got %d)", cfg->batch);
     if (cfg->height < 1 || cfg->width < 1 || cfg->height > PGX_MAX_SIDE || cfg->width > PGX_MAX_SIDE)
         return fail(PGX_E_INVALID, "map size %dx%d outside [1, %d]", cfg->height, cfg->width, PGX_MAX_SIDE);
@@ -152,7 +156,7 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
         return fail(PGX_E_INVALID, "outside_density %.3f outside [0, 1]", (double)cfg->outside_density);
     if (cfg->soft_vertex_rule < 0 || cfg->soft_vertex_rule > 1 || cfg->coop_reward < 0 || cfg->coop_reward > 1 ||
         cfg->bad_action < 0 || cfg->bad_action > 1 || cfg->lifelong_rng < 0 || cfg->lifelong_rng > 1 ||
-        cfg->soft_occupancy < 0 || cfg->soft_occupancy > 1 || cfg->reserved0 != 0)
+        cfg->soft_occupancy < 0 || cfg->soft_occupancy > 1)
         return fail(PGX_E_INVALID, "unknown semantics switch (soft_vertex_rule %d, coop_reward %d, bad_action %d, soft_occupancy %d)",
                     cfg->soft_vertex_rule, cfg->coop_reward, cfg->bad_action, cfg->soft_occupancy);
     if (cfg->obs_dtype < PGX_OBS_F32 || cfg->obs_dtype > PGX_OBS_F16)
@@ -953,7 +957,14 @@ int pgx_get_geometry(const pgx_env* e, int32_t for_rollout, pgx_geometry* out) {
     out->multi_wave = g.multi_wave ? 1 : 0;
     out->p16 = g.p16 ? 1 : 0;
     out->stagger = g.stagger;
-    out->store_policy = g.store_policy;
+    // the EFFECTIVE store flavour: the generic funnels of the lighter formats (uint8; bfloat16 / float16 with a
+    // window below 7 cells or beyond the 16-bit row masks) know plain and nontemporal stores only -- sc1 runs as plain there
+    {
+        const int W = 2 * e->cfg.obs_radius + 1;
+        const bool h16 = e->cfg.obs_dtype == PGX_OBS_BF16 || e->cfg.obs_dtype == PGX_OBS_F16;
+        const bool all_flavours = e->cfg.obs_dtype == PGX_OBS_F32 || (h16 && g.p16 && W >= 7);
+        out->store_policy = all_flavours ? g.store_policy : (g.store_policy == 1 ? 1 : 0);
+    }
     out->state_stores = g.state_stores;
     out->grid = g.grid;
     out->lds_bytes = (int32_t)g.lds_bytes;

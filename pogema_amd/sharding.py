@@ -75,23 +75,36 @@ class HostGather:
 
     All ranks of a node map one shared-memory segment laid out as `slots` x [field][global env row]; every rank registers
     it with the HIP runtime (page-locked, DMA-able) and copies its own rows of every field straight from HBM into place
-    with asynchronous D2H copies on a side stream -- the "gather" is N concurrent DMA streams into disjoint rows plus one
-    host barrier (gloo) per finished step.  Rank `dst` reads the global tensors in place.  Fields that lie back to back
-    in device memory AND in the segment travel as one copy (one rank: the engine's recycled outputs -- rewards |
+    with asynchronous D2H copies on a side stream -- the "gather" is N concurrent DMA streams into disjoint rows.  Ranks
+    synchronise through two counters per rank in the segment's header (which ticket has LANDED, which one rank dst has
+    RELEASED): no gloo call on the per-step path.  Rank `dst` reads the global tensors in place.  Fields that lie back to
+    back in device memory AND in the segment travel as one copy (one rank: the engine's recycled outputs -- rewards |
     terminated | truncated | is_active are one block -- are one 7-byte-per-agent copy per step).
 
         gather = HostGather({"rewards": ((A,), torch.float32), "terminated": ((A,), torch.bool), ...}, global_batch)
-        ticket = gather.start(rewards=rew, terminated=term, ...)   # enqueue: returns at once, the engine's stream is not held up
+        ticket = gather.start(rewards=rew, terminated=term, ...)   # returns at once, the engine's stream is not held up
         ... next step() ...
         host = gather.finish(ticket)     # rank dst: {"rewards": CPU tensor [global_batch, A], ...}; other ranks: None
 
-    A returned tensor is a view of slot `ticket % slots`: it is overwritten by the start() call `slots` steps later
-    (default 2: consume step t's outputs before starting step t+2, the contract of `reuse_buffers=True`).
-    Without a HIP device (CPU tests, gloo) the same code runs with plain host copies.  `shared=False`: private pinned
-    staging per rank + a padded gloo gather (the portable fallback, also taken when the segment cannot be registered).
-    Not thread-safe; one instance per consumer."""
+    The dependency "copy after the step that produced the data" is kept on the HOST (measured on MI355X / ROCm 7.2,
+    profiles/r5/host_gather_variants.txt: a cross-stream hipStreamWaitEvent per step more than doubles the loop time --
+    257 vs 113 us per configs[2] step --, an event the host polls costs 5-8 us): start() only records an event behind
+    the producer and keeps the source tensors referenced; the copies are issued, with no GPU-side wait, by the next
+    start() / finish() call that finds that event complete.  So the copy of step t runs under step t+1's kernel as long
+    as the caller keeps one step in the queue -- `start(t); finish(t-1)` or deeper.
 
-    def __init__(self, fields, global_batch: int, dst: int = 0, slots: int = 2, shared: bool = True, device=None):
+    Lifetime of what finish(t) returns: views of slot `t % slots`, valid until rank dst's next finish() call; a slot is
+    overwritten only by a ticket `slots` later, and start() of that ticket waits (other ranks) or raises (rank dst itself:
+    a caller bug) until dst has released it.  The unpipelined loop (start(t); finish(t)) needs 2 slots, `start(t);
+    finish(t-1)` 3 (the default), one more per extra step in flight.
+    Without a HIP device (CPU tests) the same code runs with plain host copies.  `shared=False`: private pinned staging
+    per rank + a padded gloo gather per step (the portable fallback, also taken when the segment cannot be created or
+    registered -- decided collectively).  Not thread-safe; one instance per consumer."""
+
+    HEADER = 64  # bytes per rank in the segment's header: int64 landed, int64 released (rank dst's line only)
+
+    def __init__(self, fields, global_batch: int, dst: int = 0, slots: int = 3, shared: bool = True, device=None,
+                 timeout_s: float = 120.0):
         self.fields = {k: (tuple(shape), dtype) for k, (shape, dtype) in fields.items()}
         self.global_batch, self.dst, self.slots = int(global_batch), int(dst), int(slots)
         if self.slots < 1 or not self.fields:
@@ -102,6 +115,7 @@ class HostGather:
         self._group = _host_group() if (dist.is_initialized() and self.world > 1) else None
         self._cuda = torch.cuda.is_available() and (device is None or torch.device(device).type == "cuda")
         self._device = torch.device(device) if device is not None else (torch.device("cuda", torch.cuda.current_device()) if self._cuda else torch.device("cpu"))
+        self.timeout_s = float(timeout_s)
         # layout of one slot: fields in the order given, each [global_batch, *shape], naturally aligned, no other gaps
         self._layout, off = {}, 0
         for name, (shape, dtype) in self.fields.items():
@@ -113,9 +127,11 @@ class HostGather:
             self._layout[name] = (off, row)
             off += row * self.global_batch
         self.slot_bytes = _aligned(off, 64)
-        self.nbytes = self.slot_bytes * self.slots
+        self._data0 = self.HEADER * self.world
+        self.nbytes = self._data0 + self.slot_bytes * self.slots
         self._registered = False
         self._mm = None
+        self._ctr = None
         self.shared = bool(shared) and self.world > 1
         self.mode = None
         if self.shared:
@@ -133,12 +149,11 @@ class HostGather:
             self._host = self._private_staging()
             self.mode = "private staging" + (" + gloo gather" if self.world > 1 else "")
         self._stream = torch.cuda.Stream(device=self._device) if self._cuda else None
-        self._events = [None] * self.slots
-        self._inflight = [None] * self.slots  # source tensors of a slot's copies, referenced until finish() / slot reuse:
-        #                                       a recycling producer (reuse_buffers='recycle') must not hand them out again
+        self._pending = []                    # tickets whose copies are not issued yet: [ticket, slot, jobs, ready event, sources]
+        self._issued = {}                     # ticket -> (done event or None, sources): copies in flight
         self._seq = 0
-        self._done = -1
-        self.copies_per_step = None  # statistics: D2H copies the last start() issued (after merging)
+        self._done = -1                       # latest ticket this rank has finished
+        self.copies_per_step = None  # statistics: D2H copies per start() (after merging)
 
     # -- memory ---------------------------------------------------------------------------------
     def _map_shared(self) -> torch.Tensor:
@@ -146,17 +161,19 @@ class HostGather:
         lives as long as it is mapped; nothing is left behind if a rank dies later)."""
         import mmap
         import os
+        import numpy as np
         name = [None]
+        fd = None
         if self.rank == self.dst:
             name[0] = f"/dev/shm/pgx_gather_{os.getpid()}_{id(self):x}"
-            fd = os.open(name[0], os.O_CREAT | os.O_EXCL | os.O_RDWR | getattr(os, "O_NOFOLLOW", 0), 0o600)
             try:
+                fd = os.open(name[0], os.O_CREAT | os.O_EXCL | os.O_RDWR | getattr(os, "O_NOFOLLOW", 0), 0o600)
                 os.ftruncate(fd, self.nbytes)
             except OSError:
-                os.close(fd)
-                os.unlink(name[0])
-                name[0] = None
-                fd = None
+                if fd is not None:
+                    os.close(fd)
+                    os.unlink(name[0])
+                name[0], fd = None, None
         dist.broadcast_object_list(name, src=self.dst, group=self._group)
         err = None
         try:
@@ -176,9 +193,14 @@ class HostGather:
                 pass
         if err is not None:
             raise err
+        self._ctr = np.frombuffer(self._mm, dtype=np.int64, count=self._data0 // 8)
+        self._ctr[self.rank * 8] = -1          # landed
+        if self.rank == self.dst:
+            self._ctr[self.rank * 8 + 1] = -1  # released
         host = torch.frombuffer(self._mm, dtype=torch.uint8)
         if self._cuda:
             self._register(host)
+        dist.barrier(group=self._group)  # every counter is initialised before anybody publishes a ticket
         return host
 
     def _register(self, host: torch.Tensor):
@@ -200,6 +222,7 @@ class HostGather:
                 pass
             self._registered = False
         self._host = None
+        self._ctr = None
         if self._mm is not None:
             try:
                 self._mm.close()
@@ -210,7 +233,7 @@ class HostGather:
     def close(self):
         if self._stream is not None:
             self._stream.synchronize()
-        self._views = None
+        self._pending, self._issued = [], {}
         self._unmap()
 
     def __del__(self):
@@ -220,25 +243,52 @@ class HostGather:
             pass
 
     # -- views ----------------------------------------------------------------------------------
-    def _field_view(self, slot: int, name: str, rows=None) -> torch.Tensor:
-        """[global_batch (or the given row range), *shape] view of `name` in `slot`."""
+    def _field_view(self, slot: int, name: str) -> torch.Tensor:
+        """[global_batch, *shape] view of `name` in `slot`."""
         shape, dtype = self.fields[name]
         off, row = self._layout[name]
-        lo, n = (0, self.global_batch) if rows is None else rows
-        base = slot * self.slot_bytes + off + lo * row
-        flat = self._host[base:base + n * row]
+        base = self._data0 + slot * self.slot_bytes + off
+        flat = self._host[base:base + self.global_batch * row]
         if dtype == torch.bool:
-            return flat.view(torch.bool).view((n,) + shape)
-        return flat.view(dtype).view((n,) + shape)
+            return flat.view(torch.bool).view((self.global_batch,) + shape)
+        return flat.view(dtype).view((self.global_batch,) + shape)
+
+    # -- cross-rank counters ----------------------------------------------------------------------
+    def _spin(self, cond, what: str):
+        import os
+        import time
+        t0, polls = time.monotonic(), 0
+        while not cond():
+            polls += 1
+            if polls % 64 == 0:
+                os.sched_yield()
+                if time.monotonic() - t0 > self.timeout_s:
+                    raise RuntimeError(f"HostGather rank {self.rank}: waited {self.timeout_s:.0f} s for {what}")
+
+    def _released(self) -> int:
+        """Highest ticket rank dst has given up (its views are dead)."""
+        if self._ctr is not None:
+            return int(self._ctr[self.dst * 8 + 1])
+        return self._done - 1
 
     # -- the gather -----------------------------------------------------------------------------
     def start(self, **tensors) -> int:
-        """Enqueue the copies of this rank's rows (device tensors [local batch, *shape] for every field, all of them) after
-        everything enqueued so far on the current stream; returns the ticket for finish()."""
+        """Registers the copies of this rank's rows (device tensors [local batch, *shape] for every field, all of them)
+        behind everything enqueued so far on the current stream; returns the ticket for finish()."""
         if set(tensors) != set(self.fields):
             raise ValueError(f"start() needs exactly the fields {sorted(self.fields)}")
-        slot = self._seq % self.slots
-        jobs = []  # (host byte offset, byte count, source tensor or (storage-sharing first tensor, byte count))
+        q = self._seq
+        slot = q % self.slots
+        if q >= self.slots:  # the slot still holds ticket q - slots: rank dst must have released it
+            old = q - self.slots
+            if self.rank == self.dst or self._ctr is None:
+                if old > self._done - 1:
+                    raise ValueError(f"HostGather: start() number {q} would overwrite ticket {old}, whose views are still "
+                                     f"valid (latest finished ticket: {self._done}); call finish() first or use more slots "
+                                     f"({self.slots} now)")
+            else:
+                self._spin(lambda: self._released() >= old, f"rank {self.dst} to release ticket {old}")
+        jobs = []  # [host byte offset, byte count, first source tensor, device address]
         for name in self.fields:
             t = tensors[name]
             shape, dtype = self.fields[name]
@@ -247,7 +297,7 @@ class HostGather:
                 raise ValueError(f"{name}: expected a contiguous {dtype} tensor of shape {(self.count,) + shape}, got "
                                  f"{t.dtype} {tuple(t.shape)}")
             off, row = self._layout[name]
-            jobs.append([slot * self.slot_bytes + off + self.start_row * row, self.count * row, t, t.data_ptr()])
+            jobs.append([self._data0 + slot * self.slot_bytes + off + self.start_row * row, self.count * row, t, t.data_ptr()])
         merged = [jobs[0]]
         for j in jobs[1:]:
             m = merged[-1]
@@ -257,27 +307,37 @@ class HostGather:
             else:
                 merged.append(j)
         self.copies_per_step = len(merged)
+        copies = [(hoff, nbytes, self._bytes_of(t, nbytes)) for hoff, nbytes, t, _ in merged]
+        ready = None
         if self._cuda:
             ready = torch.cuda.Event()
-            ready.record()                       # the producer stream's position now
-            self._stream.wait_event(ready)
-            prev = self._events[slot]
-            with torch.cuda.stream(self._stream):
-                for hoff, nbytes, t, _ in merged:
-                    self._host[hoff:hoff + nbytes].copy_(self._bytes_of(t, nbytes), non_blocking=True)
-                done = torch.cuda.Event()
-                done.record(self._stream)
-            for _, _, t, _ in merged:
-                t.record_stream(self._stream)    # torch's allocator: the side stream still reads it
-            if prev is not None:
-                prev.synchronize()               # (slot reuse without finish(): its old sources are released below)
-            self._events[slot] = done
-            self._inflight[slot] = tuple(tensors.values())
-        else:
-            for hoff, nbytes, t, _ in merged:
-                self._host[hoff:hoff + nbytes].copy_(self._bytes_of(t, nbytes))
+            ready.record()  # the producer stream's position now
+        # (the sources stay referenced until their copies have landed: a recycling producer must not hand them out again)
+        self._pending.append((q, copies, ready, tuple(tensors.values())))
         self._seq += 1
-        return self._seq - 1
+        self._pump()
+        return q
+
+    def _pump(self, upto: int = -1):
+        """Issues the copies of every pending ticket whose producer has finished (tickets <= `upto`: waits for it)."""
+        while self._pending:
+            q, copies, ready, sources = self._pending[0]
+            if ready is not None and not ready.query():
+                if q > upto:
+                    return
+                ready.synchronize()
+            self._pending.pop(0)
+            done = None
+            if self._cuda:
+                with torch.cuda.stream(self._stream):  # no GPU-side dependency: the host has seen the producer finish
+                    for hoff, nbytes, src in copies:
+                        self._host[hoff:hoff + nbytes].copy_(src, non_blocking=True)
+                    done = torch.cuda.Event()
+                    done.record(self._stream)
+            else:
+                for hoff, nbytes, src in copies:
+                    self._host[hoff:hoff + nbytes].copy_(src)
+            self._issued[q] = (done, sources)
 
     @staticmethod
     def _bytes_of(t: torch.Tensor, nbytes: int) -> torch.Tensor:
@@ -287,16 +347,25 @@ class HostGather:
 
     def finish(self, ticket=None):
         """Waits until the copies of `ticket` (default: the latest start()) have landed on every rank; rank dst gets
-        {field: CPU tensor [global_batch, *shape]} (views, see the class docstring), the others None."""
+        {field: CPU tensor [global_batch, *shape]} (views, see the class docstring), the others None.  Tickets must be
+        finished in increasing order (skipping is allowed: finishing t gives up everything before it)."""
         ticket = self._seq - 1 if ticket is None else int(ticket)
-        if not (0 <= ticket < self._seq) or ticket < self._seq - self.slots:
-            raise ValueError(f"ticket {ticket} is not one of the last {self.slots} start() calls")
+        if not (0 <= ticket < self._seq) or ticket < self._seq - self.slots or ticket < self._done:
+            raise ValueError(f"ticket {ticket} is not one of the last {self.slots} start() calls (or older than the latest "
+                             f"finished one, {self._done})")
         slot = ticket % self.slots
-        if self._cuda and self._events[slot] is not None:
-            self._events[slot].synchronize()
-        self._inflight[slot] = None
-        if self.world > 1 and self.shared:
-            dist.barrier(group=self._group)  # every rank's rows are in place (DMA complete + host-visible before it entered)
+        self._pump(upto=ticket)
+        for q in sorted(k for k in self._issued if k <= ticket):
+            done, _sources = self._issued.pop(q)
+            if done is not None:
+                done.synchronize()
+        self._done = max(self._done, ticket)
+        if self._ctr is not None:
+            self._ctr[self.rank * 8] = ticket              # this rank's rows of every ticket <= `ticket` are in place
+            if self.rank == self.dst:
+                self._ctr[self.rank * 8 + 1] = ticket - 1  # ... and the views of everything before it are given up
+                self._spin(lambda: all(int(self._ctr[r * 8]) >= ticket for r in range(self.world)),
+                           f"the rows of ticket {ticket} from every rank")
         if self.world > 1 and not self.shared:
             return self._finish_gloo(slot)
         if self.rank != self.dst:
@@ -313,7 +382,7 @@ class HostGather:
         spans = {}
         for name, (off, row) in self._layout.items():
             n = self.count * row
-            base = slot * self.slot_bytes + off + self.start_row * row
+            base = self._data0 + slot * self.slot_bytes + off + self.start_row * row
             packed[pos:pos + n] = self._host[base:base + n]
             spans[name] = (pos, row)
             pos += widest * row

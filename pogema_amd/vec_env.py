@@ -171,7 +171,7 @@ class VecPogema:
             coop_reward=_lib.COOP_REWARDS[self.semantics.coop_reward],
             bad_action=_lib.BAD_ACTIONS[self.semantics.bad_action],
             lifelong_rng=_lib.LIFELONG_RNGS[self.semantics.lifelong_rng],
-            soft_occupancy=_lib.SOFT_OCCUPANCY[self.semantics.soft_occupancy], reserved0=0)
+            soft_occupancy=_lib.SOFT_OCCUPANCY[self.semantics.soft_occupancy], abi_version=_lib.PGX_ABI_VERSION)
         self._handle = C.c_void_p()
         _lib.check(self._lib.pgx_create(C.byref(cfg), self.device_index, C.byref(self._handle)))
         self._bufs = None

@@ -48,6 +48,7 @@ int main(int argc, char** argv) {
     cfg.batch = B; cfg.height = S; cfg.width = S; cfg.num_agents = A; cfg.obs_radius = r;
     cfg.collision_system = collision; cfg.on_target = on_target; cfg.max_episode_steps = 7; cfg.auto_reset = 1;
     cfg.seed = seed; cfg.env_index_base = 5;
+    cfg.abi_version = PGX_ABI_VERSION;
     if (pgx_abi_version() != PGX_ABI_VERSION) return 4;
     pgx_env* env = nullptr;
     PGXCK(pgx_create(&cfg, 0, &env));

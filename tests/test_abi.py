@@ -30,9 +30,9 @@ def test_abi_version(engine_lib):
 
 
 def test_config_struct_layout():
-    # must match `struct pgx_config` in the header: 10 x int32, uint64, int64, int32, float, 6 x int32 (ABI 4)
+    # must match `struct pgx_config` in the header: 10 x int32, uint64, int64, int32, float, 6 x int32 (the last one: abi_version, ABI 6)
     assert C.sizeof(_lib.PgxConfig) == 10 * 4 + 8 + 8 + 4 + 4 + 6 * 4
-    assert _lib.PgxConfig.soft_occupancy.offset == 80 and _lib.PgxConfig.reserved0.offset == 84
+    assert _lib.PgxConfig.soft_occupancy.offset == 80 and _lib.PgxConfig.abi_version.offset == 84
     assert _lib.PgxConfig.soft_vertex_rule.offset == 64 and _lib.PgxConfig.bad_action.offset == 72
     assert _lib.PgxConfig.lifelong_rng.offset == 76
     assert _lib.PgxConfig.seed.offset == 40 and _lib.PgxConfig.env_index_base.offset == 48
@@ -44,12 +44,14 @@ def test_config_struct_layout():
     ("obs_radius", 0, "obs_radius"), ("obs_radius", 16, "obs_radius"), ("collision_system", 7, "collision"),
     ("on_target", -1, "on_target"), ("height", 0, "map size"), ("width", 4096, "map size"),
     ("soft_vertex_rule", 2, "semantics"), ("coop_reward", -1, "semantics"), ("bad_action", 3, "semantics"),
-    ("lifelong_rng", 2, "semantics"), ("soft_occupancy", 2, "semantics"), ("reserved0", 1, "semantics"),
+    ("lifelong_rng", 2, "semantics"), ("soft_occupancy", 2, "semantics"), ("abi_version", 0, "abi_version"),
+    ("abi_version", 5, "renumbered soft_occupancy"), ("abi_version", 7, "abi_version"),
     ("obs_dtype", 4, "obs_dtype"), ("obs_dtype", -1, "obs_dtype"),
 ])
 def test_create_rejects_bad_config(engine_lib, field, value, needle):
     cfg = _lib.PgxConfig(batch=4, height=8, width=8, num_agents=2, obs_radius=3, collision_system=0, on_target=0,
-                         max_episode_steps=64, auto_reset=0, obs_dtype=0, seed=0, env_index_base=0)
+                         max_episode_steps=64, auto_reset=0, obs_dtype=0, seed=0, env_index_base=0,
+                         abi_version=_lib.PGX_ABI_VERSION)
     setattr(cfg, field, value)
     handle = C.c_void_p()
     status = engine_lib.pgx_create(C.byref(cfg), 0, C.byref(handle))
@@ -59,7 +61,8 @@ def test_create_rejects_bad_config(engine_lib, field, value, needle):
 
 def test_lds_limit_is_reported(engine_lib):
     cfg = _lib.PgxConfig(batch=1, height=1024, width=1024, num_agents=64, obs_radius=15, collision_system=0,
-                         on_target=0, max_episode_steps=64, auto_reset=0, obs_dtype=0, seed=0, env_index_base=0)
+                         on_target=0, max_episode_steps=64, auto_reset=0, obs_dtype=0, seed=0, env_index_base=0,
+                         abi_version=_lib.PGX_ABI_VERSION)
     handle = C.c_void_p()
     assert engine_lib.pgx_create(C.byref(cfg), 0, C.byref(handle)) == -1
     assert "LDS" in engine_lib.pgx_last_error().decode()
@@ -88,7 +91,8 @@ def test_no_device_fails_loudly_not_silently(engine_lib):
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         VecPogema(GridConfig(num_agents=2), batch=2)
     cfg = _lib.PgxConfig(batch=4, height=8, width=8, num_agents=2, obs_radius=3, collision_system=0, on_target=0,
-                         max_episode_steps=64, auto_reset=0, obs_dtype=0, seed=0, env_index_base=0)
+                         max_episode_steps=64, auto_reset=0, obs_dtype=0, seed=0, env_index_base=0,
+                         abi_version=_lib.PGX_ABI_VERSION)
     handle = C.c_void_p()
     assert engine_lib.pgx_create(C.byref(cfg), 0, C.byref(handle)) == -2  # PGX_E_HIP
     assert not handle.value

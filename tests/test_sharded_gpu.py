@@ -124,7 +124,7 @@ def _rank(rank, world, port, tmpdir):
         # the engineered gather rides on the loop: every step's outputs (observation included here) DMA'd into the shared
         # page-locked segment by both ranks, finished one step late (pipelined) -- and the plain gather_to_host of the same
         # tensors must return the same bytes
-        hg = HostGather(step_output_fields(env, with_obs=True), GB, slots=2)
+        hg = HostGather(step_output_fields(env, with_obs=True), GB)  # (3 slots: start(t), then finish(t - 1))
         assert hg.mode == "shared segment" and hg._host.is_pinned()
         prev, per_step = None, []
         for t in range(T):

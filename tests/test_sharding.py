@@ -86,7 +86,8 @@ def _gather_worker(rank, world, port, tmpdir, shared):
         fields = {"rewards": ((A,), torch.float32), "terminated": ((A,), torch.bool), "truncated": ((A,), torch.bool),
                   "is_active": ((A,), torch.bool), "episode_done": ((), torch.bool), "metrics": ((6,), torch.float32),
                   "obs": ((A, 3, 3, 3), torch.float32)}
-        g = HostGather(fields, GB, slots=2, shared=shared)
+        g = HostGather(fields, GB, shared=shared)  # 3 slots: the pipelined loop below needs them
+        assert g.slots == 3
         assert g.mode == ("shared segment" if shared else "private staging + gloo gather")
         assert not os.path.exists("/dev/shm") or not [n for n in os.listdir("/dev/shm") if n.startswith("pgx_gather_")], \
             "the segment's name must be gone once everybody has mapped it"
@@ -173,8 +174,68 @@ def test_host_gather_single_process_merges_adjacent_fields():
     assert torch.equal(outs[0][2]["metrics"], outs[2][1]["metrics"])
     with pytest.raises(ValueError):
         g.finish(0)
+    # two slots carry an unpipelined loop only: a second start() without a finish() in between would overwrite a slot
+    # rank dst may still be reading
+    g.start(**mine)
+    with pytest.raises(ValueError, match="views are still valid"):
+        g.start(**mine)
+    g.finish()
     with pytest.raises(ValueError):
         g.start(rewards=mine["rewards"])
     with pytest.raises(ValueError):
         g.start(**dict(mine, metrics=torch.rand(B, 5)))
     g.close()
+
+
+def _ring_worker(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import random
+        import time
+        from pogema_amd.sharding import HostGather, shard_bounds
+        GB, A, T = 23, 3, 120
+        start, count = shard_bounds(GB, world, rank)
+        g = HostGather({"x": ((A,), torch.float32), "f": ((), torch.bool)}, GB, slots=3)
+        assert g.mode == "shared segment"
+        rnd = random.Random(rank)
+        rows = torch.arange(start, start + count, dtype=torch.float32)[:, None] * 1000.0
+
+        def payload(t):
+            return {"x": (rows + t + torch.arange(A, dtype=torch.float32)[None]).contiguous(),
+                    "f": ((torch.arange(start, start + count) + t) % 3 == 0)}
+
+        prev = None
+        for t in range(T):
+            if rank == 0 and t % 7 == 3:
+                time.sleep(0.004)   # a slow reader: the writers must wait for its release, not overwrite
+            elif rank != 0 and rnd.random() < 0.2:
+                time.sleep(0.002)   # a slow writer: the reader must wait for its rows, not read stale ones
+            tk = g.start(**payload(t))
+            if prev is not None:
+                got = g.finish(prev)
+                if rank == 0:
+                    want_x = torch.arange(GB, dtype=torch.float32)[:, None] * 1000.0 + prev + torch.arange(A, dtype=torch.float32)[None]
+                    want_f = (torch.arange(GB) + prev) % 3 == 0
+                    if t % 5 == 0:
+                        time.sleep(0.001)  # ... and the views must still be intact after a pause
+                    assert torch.equal(got["x"], want_x), f"ticket {prev}: rows of another step"
+                    assert torch.equal(got["f"], want_f)
+            prev = tk
+        g.finish(prev)
+        dist.barrier()
+        g.close()
+        if rank == 0:
+            open(os.path.join(tmpdir, "ring_ok"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_host_gather_ring_protocol_three_ranks(tmp_path):
+    """The shared-segment ring under uneven speeds: three ranks, 120 pipelined steps, a reader that stalls and writers that
+    stall -- every ticket's global tensors must hold exactly that step's rows (landed / released counters, no gloo call on
+    the per-step path)."""
+    port = 29500 + ((os.getpid() + 31) % 2000)
+    mp.spawn(_ring_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    assert (tmp_path / "ring_ok").exists()

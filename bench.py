@@ -324,7 +324,7 @@ def setup_groups(rank, world, device, try_rccl, fake_fail_ranks=()):
 def _walks_in_process():
     """Full-budget zone walks this process has run, over all its engines (a failed one is paid once: negative cache)."""
     from pogema_amd.buffers import WalkVerdicts
-    return WalkVerdicts.walks
+    return {"walks": WalkVerdicts.walks, "failed": WalkVerdicts.failed_walks}
 
 
 def gpu_identity(dev_index):
@@ -509,23 +509,24 @@ class EngineStep:
                 self.env.step(self.pool[self.i % len(self.pool)])
                 self.i += 1
 
-        gather = HostGather(step_output_fields(env), global_batch, device=env.device)
+        depth = 2  # steps in flight between start() and finish(): the consumer reads step t-2 while step t is enqueued
+        gather = HostGather(step_output_fields(env), global_batch, device=env.device, slots=depth + 2)
         fields_bytes = sum(row for _, row in gather._layout.values()) * gather.count
         checked = {}
 
         def gathered(n):
-            prev = None
+            pend = []
             for _ in range(n):
                 out = self.env.step(self.pool[self.i % len(self.pool)])
                 self.i += 1
-                ticket = start_step_gather(gather, out)
+                pend.append(start_step_gather(gather, out))
                 del out
-                if prev is not None:
-                    host = gather.finish(prev)
+                if len(pend) > depth:
+                    host = gather.finish(pend.pop(0))
                     if host is not None and not checked:
                         checked["rewards_sum"] = float(host["rewards"].sum())
-                prev = ticket
-            gather.finish(prev)
+            while pend:
+                gather.finish(pend.pop(0))
 
         res = {}
         for name, fn in (("loop_ms_per_step", plain), ("with_gather_ms_per_step", gathered)):
@@ -539,6 +540,7 @@ class EngineStep:
                 out.append((time.perf_counter() - t0) / steps * 1e3)
             res[name] = statistics.median(out)
         res.update(mode=gather.mode, copies_per_step=gather.copies_per_step, bytes_per_step_per_rank=fields_bytes,
+                   steps_in_flight=depth, slots=gather.slots,
                    cost_us_per_step=round((res["with_gather_ms_per_step"] - res["loop_ms_per_step"]) * 1e3, 2),
                    small_output_gbs=fields_bytes / (res["with_gather_ms_per_step"] * 1e-3) / 1e9)
         gather.close()
@@ -1029,9 +1031,10 @@ def main(argv=None):
             e = extras["host_gather"]
             e.update(what="the step loop with the host-side gather riding on it (pogema_amd.sharding.HostGather: every step's "
                           "rewards / terminated / truncated / is_active / episode_done / metrics into one page-locked host "
-                          "segment by async D2H on a side stream, finish(t-1) while step t runs; N > 1: all ranks DMA into one "
-                          "shared segment, one gloo barrier per step, no collective on the data path) against the same loop "
-                          "without it; obs_d2h_*: one observation tensor to pinned host memory, against PCIe Gen5 x16")
+                          "segment by async D2H on a side stream, issued by the host once the step's event has completed -- no "
+                          "GPU-side cross-stream wait --, finish(t-2) while step t is enqueued; N > 1: all ranks DMA into one "
+                          "shared segment, landed / released counters in its header, no collective and no gloo call per step) "
+                          "against the same loop without it; obs_d2h_*: one observation tensor to pinned host memory, against PCIe Gen5 x16")
         if "held_pair" in extras:
             e = extras["held_pair"]
             e.update(value=batch * agents / (e["ms_per_step"] * 1e-3), unit="agent-steps/s",

@@ -223,6 +223,7 @@ class WalkVerdicts:
     _lock = threading.Lock()
     _failed = {}  # device identity -> {"budget_gib", "candidates", "same_zone_us", "spacer_gib", "walks"}
     walks = 0     # statistics: full walks this process has run (any outcome), for tests and bench lines
+    failed_walks = 0  # ... and how many of them found no second zone
 
     @staticmethod
     def enabled() -> bool:
@@ -236,6 +237,7 @@ class WalkVerdicts:
             if info.get("spread"):
                 cls._failed.pop(device_identity(device_index), None)
                 return
+            cls.failed_walks += 1
             key = device_identity(device_index)
             prev = cls._failed.get(key)
             cls._failed[key] = {"budget_gib": max(float(budget_gib), prev["budget_gib"] if prev else 0.0),

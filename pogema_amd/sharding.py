@@ -339,6 +339,23 @@ class HostGather:
                     self._host[hoff:hoff + nbytes].copy_(src)
             self._issued[q] = (done, sources)
 
+    def snapshot_pair(self, flags: torch.Tensor, values: torch.Tensor):
+        """Copies of a bool/uint8 tensor and a float32 tensor (the engine-owned episode_done [B] and metrics [B, 6]) in ONE
+        device launch, back to back in a buffer that belongs to the slot the next start() will use -- safe to rewrite
+        because that slot's previous ticket has been finished by then (start() checks)."""
+        slot = self._seq % self.slots
+        if not hasattr(self, "_snaps"):
+            self._snaps = {}
+        nf, nv = flags.numel() * flags.element_size(), values.numel() * values.element_size()
+        off = _aligned(nf, values.element_size())
+        buf = self._snaps.get(slot)
+        if buf is None or buf.numel() != off + nv or buf.device != flags.device:
+            buf = self._snaps[slot] = torch.empty(off + nv, dtype=torch.uint8, device=flags.device)
+        f = buf[:nf].view(flags.dtype).view(flags.shape)
+        v = buf[off:off + nv].view(values.dtype).view(values.shape)
+        torch._foreach_copy_([buf[:nf], buf[off:off + nv]], [flags.reshape(-1).view(torch.uint8), values.reshape(-1).view(torch.uint8)])
+        return f, v
+
     @staticmethod
     def _bytes_of(t: torch.Tensor, nbytes: int) -> torch.Tensor:
         """`nbytes` raw bytes starting at t's first element (may run past t into its neighbours in the same storage)."""
@@ -402,12 +419,12 @@ class HostGather:
 def start_step_gather(gather: "HostGather", step_result, with_obs: bool = False) -> int:
     """`gather.start` for the tuple `VecPogema.step` returned.  rewards / terminated / truncated / is_active (and obs) are
     the caller's tensors; infos['episode_done'] and infos['metrics'] are ENGINE-owned and rewritten by the next step, so
-    they are snapshotted on the producer stream first (two tiny device copies) -- the D2H then cannot race the next step."""
+    they are snapshotted on the producer stream first -- ONE fused device copy into a per-slot buffer in which they lie
+    back to back (and so travel as one D2H copy) -- the D2H then cannot race the next step."""
     obs, rewards, terminated, truncated, infos = step_result
     t = {"rewards": rewards, "terminated": terminated, "truncated": truncated, "is_active": infos["is_active"]}
     if "episode_done" in gather.fields:
-        t["episode_done"] = infos["episode_done"].clone()
-        t["metrics"] = infos["metrics"].clone()
+        t["episode_done"], t["metrics"] = gather.snapshot_pair(infos["episode_done"], infos["metrics"])
     if with_obs:
         t["obs"] = obs
     return gather.start(**t)

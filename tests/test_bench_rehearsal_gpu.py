@@ -141,7 +141,7 @@ def test_a_failed_walk_is_paid_once_by_the_whole_bench():
                        env=_env(PGX_ZONE_SCAN="1", PGX_ZONE_SPACER_GIB="24"))
     line = _line(p)
     rf = line["roofline"]
-    assert rf["zone_walks_in_process"] == 1, rf["zone_walks_in_process"]
+    assert rf["zone_walks_in_process"] == {"walks": 1, "failed": 1}, rf["zone_walks_in_process"]
     assert rf["placement"]["spread"] is False and rf["placement"]["walk_candidates"] == 3
     assert rf["box_store_stream_gbs"] and rf["frac_of_box_store_stream"] == pytest.approx(rf["achieved"] / rf["box_store_stream_gbs"])
     sec = line["secondary"]

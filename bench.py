@@ -8,7 +8,7 @@ synthetic input: BASELINE.json configs[2] by default -- 8192 envs per GPU, 64x64
 density 0.3, random-obstacle maps, uniform random actions already resident in HBM.
 Metric: agent-steps/sec, whole job = (envs over all ranks) * agents * K / max-over-ranks wall time of K steps.
 
-Launch contract (DESIGN.md section 7):
+Launch contract (DESIGN.md section 9):
   * under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` every process is one rank
     (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment); WORLD_SIZE must equal --gpus;
   * `python bench.py --gpus N` with N > 1 and no WORLD_SIZE starts the N ranks ITSELF (one child process per device,
@@ -16,7 +16,7 @@ Launch contract:
     line whose n_gpus differs from --gpus;
   * the batch shards over the ranks with no data-path collective; torch.distributed (RCCL) carries the barriers, the
     max-over-ranks clock and the per-rank kernel times only.
-Rehearsal (DESIGN.md section 7): the builder's boxes have ONE GPU, so the N > 1 flow cannot be measured there -- but it
+Rehearsal (DESIGN.md section 9): the builder's boxes have ONE GPU, so the N > 1 flow cannot be measured there -- but it
 can be EXECUTED: with PGX_BENCH_SHARE_DEVICE=1 rank r runs on device r % device_count (all ranks on cuda:0 of a 1-GPU
 box), torch.distributed uses gloo (RCCL refuses two ranks on one device) with host tensors for the clock / kernel-time
 exchange, every rank's zone walk is bounded to its share of the free memory, and the line is labelled REHEARSAL -- real
@@ -140,7 +140,7 @@ def cpu_baseline(size, agents, r, collision, density, max_steps, target_seconds=
 
 
 # ----------------------------------------------------------------------------------------------------------
-# box fingerprint: what kind of MI355X is this?  (DESIGN.md 4b: boxes of one pool differ by 25 % in store bandwidth and
+# box fingerprint: what kind of MI355X is this?  (DESIGN.md section 6: boxes of one pool differ by 25 % in store bandwidth and
 # some show no HBM "zones" at all -- the fingerprint lets such boxes be told apart by something other than timing)
 # ----------------------------------------------------------------------------------------------------------
 def _read(path, limit=4096):
@@ -988,7 +988,7 @@ def main(argv=None):
                                             "by this process"),
                          "peak_note": "8000 GB/s = HBM3E spec (MI355X_MICROARCH.md); the guide's 6.29 TB/s is a float4 COPY "
                                       "(read + write); this kernel is a write-only stream, and bare store streams reach "
-                                      "6.7-7.0 TB/s on this pool (DESIGN.md 4b, roofline.box_store_stream_gbs)",
+                                      "6.7-7.0 TB/s on this pool (DESIGN.md section 6, roofline.box_store_stream_gbs)",
                          "placement": None if args.stub else step.placement_fields(),
                          "kernel": "pgx::step_kernel", "kernel_ms": kernel_ms, "kernel_ms_per_rank": per_rank_kernel,
                          "kernel_ms_windows": kernel,

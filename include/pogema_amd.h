@@ -5,7 +5,7 @@
  * is pure Python and exposes no FFI; the entry points below are what a ctypes binding for
  * `pogema/grid.py` + `pogema/envs.py` (reset()/step()) binds instead of the per-agent Python loops.
  * The mounted reference is a stub (/root/reference/README.md:3,5 -- "code is hosted elsewhere"), so
- * upstream files are cited by name only, never by line; see DESIGN.md "Parity status".
+ * upstream files are cited by name only, never by line; see DESIGN.md section 2.
  *
  * Conventions
  *   - every function returns an int status: 0 = ok, negative = error (PGX_E_*); nothing throws
@@ -212,7 +212,7 @@ int pgx_step(pgx_env* env, const void* actions, int action_dtype, void* obs, flo
 
 /* How pgx_step's workgroups (one per environment, or per group of small environments) are shared out over the 8 XCDs:
  * shares[x] of them run on XCD x (host pointer, 8 entries).  Equal by default.  The XCDs do not get through their
- * observation streams equally fast (the odd ones lag 5-15 %, DESIGN.md section 4), and with equal shares the fast ones
+ * observation streams equally fast (the odd ones lag 5-15 %, DESIGN.md section 5), and with equal shares the fast ones
  * idle at the end of every launch: pgx_xcd_tune() runs the observation pass into `obs` and `obs_alt` in turn (the buffers
  * pgx_step will write; obs_alt may be NULL) a few times, reads when each XCD finished its share, shifts work towards the fast ones and keeps the shares that gave
  * the shortest launch (never worse than equal: equal is the first candidate).  Synchronises `stream`; nothing in the
@@ -251,7 +251,7 @@ int pgx_get_geometry(const pgx_env* env, int32_t for_rollout, pgx_geometry* out)
  * -- for callers that have the actions up front (executing MAPF plans, scripted or random policies, replaying recorded
  * episodes): upstream, the `for t in range(K): env.step(actions[t])` loop around `Pogema.step`.  Every workgroup takes its
  * own environments through all K steps, so there is no launch boundary between steps and one wave's collision resolve
- * runs under the other waves' observation streams (DESIGN.md section 4c).  All pointers are device pointers.
+ * runs under the other waves' observation streams (DESIGN.md section 7).  All pointers are device pointers.
  *   actions       [steps, batch, agents] of action_dtype, or NULL: the engine's uniform random policy -- action
  *                 (h >> 32) * 5 >> 32 of a splitmix64 chain over (policy_seed, cfg.env_index_base + env, agent,
  *                 policy_step0 + t), the same whatever the sharding; written to actions_out ([steps, batch, agents] i8)
@@ -370,7 +370,7 @@ int pgx_buffers_drop(pgx_buffers* pool, int index);  /* releases the memory of O
 int pgx_buffers_get_info(pgx_buffers* pool, pgx_buffers_info* info);
 int pgx_buffers_destroy(pgx_buffers* pool);          /* synchronises the device, then unmaps and frees        */
 /* Address space (bytes) this process has reserved for pool buffers so far.  These ranges are never handed back to the
- * driver nor re-used (ROCm 7.2 keeps stale translations either way: DESIGN.md 4b, profiles/r3/vmm_va_remap_stale.txt),
+ * driver nor re-used (ROCm 7.2 keeps stale translations either way: DESIGN.md section 6, profiles/r3/vmm_va_remap_stale.txt),
  * so the figure grows by count x stride with every pool -- out of 128 TiB; a caller that builds pools in a loop can
  * watch it here.  The probe chunks of the zone walk are plain hipMalloc memory and do not count. */
 int64_t pgx_buffers_va_reserved(void);

@@ -43,7 +43,7 @@ _MASK64 = 0xFFFFFFFFFFFFFFFF
 # ----------------------------------------------------------------------------------------------
 # Lifelong target RNG.  The reference draws from per-agent numpy PCG64 generators
 # (SURVEY A7); that stream cannot be reproduced without the source, so the build defines its own
-# counter-based generator.  It is part of the build's SPEC (DESIGN.md "lifelong RNG") and is
+# counter-based generator.  It is part of the build's SPEC (docs/SPEC.md S5, lifelong stream) and is
 # shared verbatim by oracle/pogema_oracle.c and the HIP kernel.
 # ----------------------------------------------------------------------------------------------
 def splitmix64(z: int) -> int:
@@ -434,7 +434,7 @@ class PogemaOracle:
 
     def _compute_metrics(self, step, was_on_goal, finished):
         """Metric wrappers restated (recollection of upstream `pogema/wrappers/metrics.py`, conf. med --
-        DESIGN.md open question 9): ISR / CSR / ep_length / SoC / makespan for disappearing agents,
+        docs/SPEC.md Q9): ISR / CSR / ep_length / SoC / makespan for disappearing agents,
         their 'NonDisappear' forms for on_target='nothing', avg_throughput for lifelong."""
         n = self.num_agents
         if self.on_target == "finish":

@@ -1,7 +1,7 @@
 """Zone-aware observation buffers (pgx_buffers_* of the C-ABI) as torch tensors.
 
 On MI355X a store stream confined to one physical zone of HBM sustains ~5.5 TB/s, the same stream with half of its
-bytes in another zone ~6.9 TB/s (DESIGN.md "placement"; profiles/r2/placement_*.txt).  `ZoneBuffers` asks the engine
+bytes in another zone ~6.9 TB/s (profiles/r2/placement_*.txt).  `ZoneBuffers` asks the engine
 for buffers whose two halves are backed by different zones (one contiguous virtual range each) and exposes them as
 torch tensors through `__cuda_array_interface__` -- torch only wraps the pointer, the memory belongs to the pool and is
 released when the last tensor AND the pool object are gone.
@@ -264,7 +264,7 @@ class ParkedBuffers:
     """Process-wide shelf for the observation buffers of CLOSED environments (reuse_buffers='recycle').
 
     Picking zone-spread buffers costs a walk of 1-3 s, and a pool's address ranges are never handed back to the driver
-    (DESIGN.md 4b), so a process that creates environments in a loop -- sweeps, test suites, evaluation workers --
+    (DESIGN.md section 6), so a process that creates environments in a loop -- sweeps, test suites, evaluation workers --
     would pay the walk and leak address space every time.  Instead `VecPogema.close()` parks the zone-spread buffers
     nobody references any more, still mapped, and the next environment with the same observation tensor on the same
     device takes them over without a walk.

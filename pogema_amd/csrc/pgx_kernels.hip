@@ -40,7 +40,7 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
     return z ^ (z >> 31);
 }
 
-// DESIGN.md "lifelong RNG": uniform index in [0, n) for (seed, global env, agent, counter).
+// docs/SPEC.md S5, lifelong stream: uniform index in [0, n) for (seed, global env, agent, counter).
 __device__ __forceinline__ uint32_t lifelong_draw(uint64_t seed, uint64_t env_index, uint32_t agent,
                                                   uint32_t counter, uint32_t n) {
     uint64_t h = splitmix64(seed);
@@ -421,7 +421,7 @@ __device__ __forceinline__ void stream_rows16_edges(float* out, const uint16_t* 
 //                 and the observation write.
 //   P16         : window side <= 16: row masks are packed to 16 bits, staged through registers and
 //                 written OVER the (by then dead) bitmaps and exchange arrays, so the LDS footprint is
-//                 max(state, rows) and many waves stay resident per CU (DESIGN.md "occupancy").
+//                 max(state, rows) and many waves stay resident per CU (residency).
 // ------------------------------------------------------------------------------------------------
 enum { MISC_FLAGS = 0, MISC_ARRIVED = 16, MISC_UNSOLVED = 17, MISC_OFFGOAL = 18, MISC_WORDS = 32 };
 

@@ -54,7 +54,7 @@ class VecPogema:
                 'metrics': float32 [batch, 6] (ISR, CSR, ep_length, SoC, makespan, avg_throughput; a row is
                 refreshed on the step where its env's episode ends -- mask with 'episode_done')}
 
-    Where the observation tensor lives in HBM decides up to a fifth of the step time (DESIGN.md 4b: the same kernel runs
+    Where the observation tensor lives in HBM decides up to a fifth of the step time (DESIGN.md section 6: the same kernel runs
     117..153 us per configs[2] step depending on its output buffer), so the engine allocates it (`reuse_buffers`):
       "recycle" (default)  ordinary tensors, never overwritten behind your back: a few zone-spread buffers are handed
                   out in turn and taken back only when you have dropped every reference to a tensor (and its views), as
@@ -459,7 +459,7 @@ class VecPogema:
 
     # Placement of the double-buffered observation tensors (reuse_buffers=True).  Physical HBM on MI355X falls into a
     # few large zones; a store stream confined to one zone sustains ~5.5 TB/s, the same stream with half of its bytes in
-    # another zone ~6.9 TB/s (DESIGN.md "placement", profiles/r2/placement_*.txt).  A plain allocation is physically
+    # another zone ~6.9 TB/s (profiles/r2/placement_*.txt).  A plain allocation is physically
     # compact -- one zone, unless it straddles a boundary by luck (round 1 searched for such lucky buffers by timing up
     # to 64 candidates).  The engine's buffer pool (pgx_buffers_create) REQUESTS the placement instead: each buffer is
     # one virtual range whose second half is backed by another zone, verified by timing.  Buffers below 128 MiB (a

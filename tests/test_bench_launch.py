@@ -1,4 +1,4 @@
-"""CPU: bench.py's launch contract (DESIGN.md section 7).  `--gpus N` without torchrun must start N ranks itself or
+"""CPU: bench.py's launch contract (DESIGN.md section 9).  `--gpus N` without torchrun must start N ranks itself or
 fail loudly -- never print a line for fewer GPUs than asked.  The multi-rank flow (barriers, max-over-ranks clock,
 per-rank kernel times, median of windows, the JSON contract) is driven with `--stub` (a host sleep instead of the
 engine, gloo instead of RCCL; such a line says data = "stub")."""

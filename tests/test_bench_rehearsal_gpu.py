@@ -1,4 +1,4 @@
-"""GPU: bench.py's multi-rank flow EXECUTED with real engines on a 1-GPU box (DESIGN.md section 7, "rehearsal").
+"""GPU: bench.py's multi-rank flow EXECUTED with real engines on a 1-GPU box (DESIGN.md section 9, "rehearsal").
 
 The driver's 8-GPU run is the first time `bench.py --gpus N` meets N devices; everything around the engines -- the
 launcher, rank-to-device mapping, barriers, the max-over-ranks clock, the gather of per-rank kernel times, N concurrent

@@ -1,7 +1,7 @@
 """CPU (no GPU): the closed-form collision rules the HIP kernel evaluates (pgx_kernels.hip phase 2: all-pairs
 okey/ckey sweep + pointer-doubling closure) restated in numpy-free Python and checked with hypothesis against the
 LITERAL algorithms of the oracle (sequential `priority`, dict-based `block_both`, dict/recursion `soft`) on random
-crowded scenarios.  This is the derivation DESIGN.md section 4 states, machine-checked on tens of thousands of cases;
+crowded scenarios.  This is the derivation DESIGN.md section 5 states, machine-checked on tens of thousands of cases;
 tests/test_parity_gpu.py then checks the kernel itself."""
 import numpy as np
 import pytest

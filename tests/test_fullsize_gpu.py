@@ -76,7 +76,7 @@ def assert_bench_geometry(env, workload):
 
 
 def test_bench_geometry_is_what_design_md_says():
-    """DESIGN.md section 4's table of launch shapes, as chosen by step_geometry() for bench.py's engines."""
+    """DESIGN.md section 5's table of launch shapes, as chosen by step_geometry() for bench.py's engines."""
     want = {  # workload: (lanes_per_env, envs_per_wave, waves, p16, store_policy)
         "cfg1": (8, 1, 1, 1, 2), "cfg2": (64, 1, 3, 1, 1), "cfg3": (16, 1, 1, 1, 2), "cfg4": (64, 1, 4, 1, 1)}
     for workload, shape in want.items():

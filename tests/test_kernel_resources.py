@@ -1,6 +1,6 @@
 """CPU (hipcc cross-compiles gfx950 here): register / scratch / occupancy budget of the step kernels.
 
-The single-wave step kernels must keep 8 waves per SIMD resident (DESIGN.md section 4: residency matters more than
+The single-wave step kernels must keep 8 waves per SIMD resident (DESIGN.md section 5: residency matters more than
 anything else) -- at most 64 VGPRs and 80-odd SGPRs -- and must not spill: an innocent extra branch inside the
 specialised row-mask instances once cost 430-456 bytes of scratch per lane without any test noticing (round 4, the
 16-bit observation formats).  `tools/resource_usage.py` reads hipcc's -Rpass-analysis=kernel-resource-usage remarks."""
@@ -70,7 +70,7 @@ def test_step_kernels_do_not_spill_and_keep_eight_waves_per_simd(usage):
 
 
 def test_rollout_kernels_stay_within_their_known_budget(usage):
-    """The rollout kernels sit at the 64-VGPR cap with a little scratch: pin the order of
+    """The rollout kernels sit at the 64-VGPR cap with a little scratch (docs/DESIGN_HISTORY_r1-r4.md section 8): pin the order of
     magnitude so that a regression like the one above shows."""
     for (name, G, mw, p16), (sgpr, vgpr, scratch, occ) in usage.items():
         if name != "rollout_kernel":

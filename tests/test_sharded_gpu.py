@@ -1,4 +1,4 @@
-"""GPU: the N > 1 path with REAL HIP engines on the one device a test box has (SURVEY.md 8e, DESIGN.md section 7).
+"""GPU: the N > 1 path with REAL HIP engines on the one device a test box has (SURVEY.md 8e, DESIGN.md section 9).
 
 (a) BASELINE.json configs[3] at its stated size -- 65536 environments of 32x32 / 16 agents -- as the 8 shards
     `sharding.shard_bounds(65536, 8, r)` gives the 8 GPUs of a node, run one after the other on cuda:0: every shard

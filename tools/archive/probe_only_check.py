@@ -1,6 +1,6 @@
 """What a default-constructed VecPogema does on a device that is NOT its own (here: 40 GiB of it already taken by this very
 process): the probe-only placement of round 4 -- nothing held, one probe pair -- and what the configs[2] step then costs,
-next to fresh torch tensors per step and an explicit walk.   python tools/probe_only_check.py"""
+next to fresh torch tensors per step and an explicit walk.   python tools/archive/probe_only_check.py"""
 import os
 import sys
 import time

@@ -1,7 +1,7 @@
 """Diagnostic: does the map of fast / slow pairings change between two zone walks of ONE process?  Builds N pools one
 after the other (each destroyed before the next), every walk run to the end of its budget (PGX_ZONE_SCAN=1), and prints
 one line of probe times per pool.  If consecutive walks of a process see different maps, a failed walk is worth repeating.
-    python tools/zone_retry.py [pools=4] [budget_gib=136]"""
+    python tools/archive/zone_retry.py [pools=4] [budget_gib=136]"""
 import os
 import re
 import subprocess

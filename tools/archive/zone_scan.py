@@ -2,7 +2,7 @@
 candidate (PGX_ZONE_SCAN=1), one probe time per 8 GiB of spacers: the map of "which stretches of the allocation order pair
 fast with where this process's first allocation landed".  One line per process; run it several times per lease -- the
 starting point differs from process to process on the same GPU (profiles/r4/box_fingerprints.md).
-    python tools/zone_scan.py [budget_gib=all]"""
+    python tools/archive/zone_scan.py [budget_gib=all]"""
 import os
 import re
 import subprocess

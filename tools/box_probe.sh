@@ -1,7 +1,7 @@
 #!/bin/bash
 # What kind of box is this lease?  (VERDICT r3 #3a)  Run BEFORE a benchmark on the same gpurun call and keep the output
 # next to the bench line: partition modes (compute SPX/CPX..., memory NPS1/NPS4...), VRAM vendor / size, the KFD memory
-# banks, firmware -- so that "zone" and "no-zone" boxes (DESIGN.md 4b) can be told apart by something other than timing.
+# banks, firmware -- so that "zone" and "no-zone" boxes (DESIGN.md section 6) can be told apart by something other than timing.
 #   tools/box_probe.sh [out.json]        default: gpurun_out/box_fingerprint.json
 # bench.py embeds the sysfs part of this in every JSON line (`box`); this script adds what needs the smi tools.
 cd "$(dirname "$0")/.." || exit 1

@@ -18,16 +18,17 @@ def find(pattern):
 
 
 def counter_per_launch(dirname, counter, kernel_substr):
-    path = find(f"{dirname}/**/*counter_collection.csv")
-    if not path:
+    paths = sorted(glob.glob(os.path.join(out, f"{dirname}/**/*counter_collection.csv"), recursive=True))
+    if not paths:
         return None
     per_dispatch = {}
-    with open(path) as f:
-        for row in csv.DictReader(f):
-            if row.get("Counter_Name") != counter or kernel_substr not in row.get("Kernel_Name", ""):
-                continue
-            key = row.get("Dispatch_Id")
-            per_dispatch[key] = per_dispatch.get(key, 0.0) + float(row["Counter_Value"])
+    for path in paths:  # (several passes may share a directory: one file per process)
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if row.get("Counter_Name") != counter or kernel_substr not in row.get("Kernel_Name", ""):
+                    continue
+                key = (path, row.get("Dispatch_Id"))
+                per_dispatch[key] = per_dispatch.get(key, 0.0) + float(row["Counter_Value"])
     if not per_dispatch:
         return None
     vals = list(per_dispatch.values())
@@ -65,8 +66,39 @@ for wl in wls:
         try:
             with open(bench) as f:
                 summary["bench_line"] = json.loads(f.readline())
+            pl = (summary["bench_line"].get("roofline") or {}).get("placement") or {}
+            summary["placement_tier"] = "zone" if pl.get("spread") else "nozone"
         except Exception:
             pass
+    # write-request stall counters of the step kernel (one pass, product placement): sums over the TCC channel instances
+    # per launch, and the stalled share of the write requests' cycles
+    stall = {}
+    for ctr in ("TCC_EA0_WRREQ_DRAM_CREDIT_STALL", "TCC_EA0_WRREQ_STALL", "TCC_EA0_WRREQ"):
+        c = counter_per_launch(f"{wl}_STALL", ctr, "step_kernel")
+        if c:
+            stall[ctr] = c
+    if stall:
+        sb = os.path.join(out, f"{wl}_stall_bench.json")
+        line = None
+        if os.path.exists(sb):
+            try:
+                with open(sb) as f:
+                    line = json.loads(f.readline())
+            except Exception:
+                line = None
+        rf = (line or {}).get("roofline") or {}
+        summary["write_stalls"] = {
+            "per_launch": stall,
+            "dram_credit_stall_cycles_per_wrreq": (stall["TCC_EA0_WRREQ_DRAM_CREDIT_STALL"]["mean"] / stall["TCC_EA0_WRREQ"]["mean"])
+            if "TCC_EA0_WRREQ" in stall and "TCC_EA0_WRREQ_DRAM_CREDIT_STALL" in stall and stall["TCC_EA0_WRREQ"]["mean"] else None,
+            "wrreq_stall_cycles_per_wrreq": (stall["TCC_EA0_WRREQ_STALL"]["mean"] / stall["TCC_EA0_WRREQ"]["mean"])
+            if "TCC_EA0_WRREQ" in stall and "TCC_EA0_WRREQ_STALL" in stall and stall["TCC_EA0_WRREQ"]["mean"] else None,
+            "pass_kernel_ms": rf.get("kernel_ms"), "pass_spread": (rf.get("placement") or {}).get("spread"),
+            "pass_box_store_stream_gbs": rf.get("box_store_stream_gbs"),
+            "note": "counters are summed over all TCC channel instances per launch of pgx::step_kernel; collected in their own "
+                    "rocprofv3 pass (--kernel-trace --pmc only) with the product's placement, so pass_spread says which tier "
+                    "THIS pass ran on",
+        }
     with open(os.path.join(out, f"{wl}_pmc_summary.json"), "w") as f:
         json.dump(summary, f, indent=1)
     print(wl, {k: summary.get(k) for k in ("FETCH_SIZE_kb_mean", "WRITE_SIZE_kb_mean", "hbm_bytes_per_launch")})

@@ -14,8 +14,10 @@ Launch contract:
   * `python bench.py --gpus N` with N > 1 and no WORLD_SIZE starts the N ranks ITSELF (one child process per device,
     before this process touches the GPU) and fails loudly when the box has fewer than N devices -- it never prints a
     line whose n_gpus differs from --gpus;
-  * the batch shards over the ranks with no data-path collective; torch.distributed (RCCL) carries the barriers, the
-    max-over-ranks clock and the per-rank kernel times only.
+  * the batch shards over the ranks with no data-path collective; the default process group is gloo (agreement,
+    per-rank records, set-up of the host gather), an RCCL group on top of it carries the barriers, the max-over-ranks
+    clock and the per-rank kernel times -- or gloo does, if RCCL is unusable on ANY rank (decided collectively,
+    setup_groups); every rank's GPU, placement and kernel time is in the line (roofline.per_rank).
 Rehearsal: the builder's boxes have ONE GPU, so the N > 1 flow cannot be measured there -- but it
 can be EXECUTED: with PGX_BENCH_SHARE_DEVICE=1 rank r runs on device r % device_count (all ranks on cuda:0 of a 1-GPU
 box), torch.distributed uses gloo (RCCL refuses two ranks on one device) with host tensors for the clock / kernel-time
@@ -926,6 +928,9 @@ def main(argv=None):
             hg = step.measure_host_gather(min(args.steps, 200), total_envs, with_dist=True)
         except Exception as exc:  # noqa: BLE001
             hg = {"error": repr(exc)}
+        if rehearsal:
+            hg["rehearsal"] = (f"{world} ranks time-share ONE device, one copy engine set and one PCIe link here: the figures show "
+                               f"that the shared-segment gather runs, not what it costs on {world} GPUs")
         extras["host_gather"] = hg
 
     if rank == 0:

@@ -185,15 +185,6 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
     // pgx_rollout's launch shape: the same, minus the helper waves of large launches (step_geometry())
     e->geo_roll = pgx::step_geometry(cfg->batch, A, e->bmw, e->W, !(e->flags & 2u), epw_override,
                                      obs_elem_bytes(cfg->obs_dtype), waves_override, true);
-    if (const char* f = getenv("PGX_TAIL")) {  // EXPERIMENT "W:permille": W waves per workgroup, kept only by the last permille
-        int w = 0, pm = 0;
-        if (sscanf(f, "%d:%d", &w, &pm) == 2 && e->geo.multi_wave && A <= 64 && w > e->geo.waves && w <= 16 && pm > 0 && pm <= 1000) {
-            const int early = e->geo.waves;
-            e->geo = pgx::step_geometry(cfg->batch, A, e->bmw, e->W, !(e->flags & 2u), epw_override, obs_elem_bytes(cfg->obs_dtype), w);
-            e->geo.early_waves = early;
-            e->geo.tail_permille = pm;
-        }
-    }
     for (pgx::StepGeometry* g : {&e->geo, &e->geo_roll}) {
         if (const char* f = getenv("PGX_STAGGER")) g->stagger = atoi(f);  // tuning/diagnostic override
         if (const char* f = getenv("PGX_STORE")) {  // tuning/diagnostic override: plain | nt | sc1
@@ -647,10 +638,6 @@ static void fill_params(const pgx_env* e, pgx::StepParams& p) {
         p.xcd_n[x] = e->geo.xcd_n[x];
         p.xcd_base[x] = e->geo.xcd_base[x];
     }
-    if (e->geo.early_waves > 0) {  // EXPERIMENT (PGX_TAIL)
-        p.early_nt = 64 * e->geo.early_waves;
-        p.tail_start = e->geo.grid - (((int)((int64_t)e->geo.grid * e->geo.tail_permille / 1000)) & ~7);
-    }
     p.obs_u8 = e->cfg.obs_dtype == PGX_OBS_U8 ? 1 : 0;
     p.obs_one = e->cfg.obs_dtype == PGX_OBS_BF16 ? 0x3F80u : e->cfg.obs_dtype == PGX_OBS_F16 ? 0x3C00u : 0u;
     p.soft_rule = c.soft_vertex_rule;
@@ -743,7 +730,6 @@ int pgx_rollout(pgx_env* e, int32_t steps, const pgx_rollout_io* io, void* strea
         rp.obs_stride = io->obs_slot_stride;
     }
     p.epw = e->geo_roll.epw;
-    p.early_nt = 0;
     p.stagger = e->geo_roll.stagger;
     p.store_policy = e->geo_roll.store_policy;
     p.state_stores = e->geo_roll.state_stores;

@@ -79,8 +79,6 @@ struct StepParams {
     int32_t bad_action;   // PGX_BAD_ACTION_* (Q7)
     int32_t xcd_n[8];     // workgroups (= environment slices) given to each XCD, proportional to its measured store rate
     int32_t xcd_base[8];  // first slice of each XCD (prefix sums of xcd_n): the slices of one XCD stay contiguous
-    int32_t early_nt;   // EXPERIMENT (PGX_TAIL, round 5): > 0: workgroups dispatched before `tail_start` keep only their first
-    int32_t tail_start; //   early_nt threads (the other waves exit at once); the last workgroups of the launch run all of them
     uint32_t flags;    // diagnostic switches (PGX_FLAGS env var at pgx_create): bit1 generic row path, bit2 time stamps, bit3 identity block mapping
     uint64_t seed;
     int64_t env_index_base;
@@ -135,8 +133,6 @@ struct StepGeometry {
     int epw;          // environments per wave (1 when multi_wave)
     bool multi_wave;  // num_agents > 64: one environment per workgroup
     bool p16;         // window side <= 16: packed 16-bit row masks aliased over the LDS state
-    int early_waves = 0;   // EXPERIMENT (PGX_TAIL): waves kept by the workgroups outside the launch's tail (0 = all)
-    int tail_permille = 0; //   share of the launch's workgroups (dispatched last) that run all `waves`
     int stagger;      // > 0: odd wave slots sleep this many x 8128 cycles after issuing their loads
     int store_policy; // observation store flavour (pgx_kernels.hip: store_obs16)
     int state_stores; // when the per-step result stores are issued (pgx_kernels.hip: emit_state)

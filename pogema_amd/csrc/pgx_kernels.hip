@@ -435,12 +435,7 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
 
     const int tid = threadIdx.x;
-    // EXPERIMENT (PGX_TAIL): the launch is made of workgroups with MORE helper waves than the steady state wants; the
-    // workgroups dispatched early drop the surplus waves at once (before any barrier: ended waves leave the barrier
-    // count), the last ones of the launch -- which stream into an emptying chip -- keep them and finish in half the time.
-    const bool early_wg = MW && p.early_nt > 0 && (int)blockIdx.x < p.tail_start;
-    const int NT = MW ? (early_wg ? p.early_nt : (int)blockDim.x) : 64;
-    if (MW && tid >= NT) return;
+    const int NT = MW ? (int)blockDim.x : 64;
     const int lane = tid & 63;
     const int wave = MW ? (tid >> 6) : 0;
     const int nw = NT >> 6;

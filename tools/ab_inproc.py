@@ -22,7 +22,7 @@ envs = []
 from pogema_amd import _lib as _L0  # noqa: E402
 DEFAULT_LIB = _L0.LIB_PATH
 for v in variants:
-    for k in ("PGX_FLAGS", "PGX_EPW", "PGX_STAGGER", "PGX_LDS_MIN", "PGX_WAVES", "PGX_STORE", "PGX_TEAM", "PGX_STATE_STORES", "PGX_GATE_NS", "PGX_XCD_SKEW", "PGX_TAIL"):
+    for k in ("PGX_FLAGS", "PGX_EPW", "PGX_STAGGER", "PGX_LDS_MIN", "PGX_WAVES", "PGX_STORE", "PGX_TEAM", "PGX_STATE_STORES", "PGX_GATE_NS", "PGX_XCD_SKEW"):
         os.environ.pop(k, None)
     lib_path = None
     for kv in v.split(","):

@@ -384,6 +384,8 @@ def test_closed_environments_leave_their_buffers_to_the_next_one(monkeypatch):
     b.close()
     assert key not in ParkedBuffers._shelf and ParkedBuffers.bytes_parked() == 0  # one of two: not a set -> nothing is kept
 
+    from pogema_amd.buffers import WalkVerdicts
+    WalkVerdicts.clear()  # (on a lease where `a`'s walk found no second zone the negative cache would send `c` to probe-only)
     c = VecPogema(cfg, batch=B, auto_reset=True, placement_budget_gib="half")  # nothing parked: its own walk
     c.reset(seed=3)
     assert c.placement["method"] == "pgx_buffers (two HBM zones per buffer)"
@@ -392,6 +394,7 @@ def test_closed_environments_leave_their_buffers_to_the_next_one(monkeypatch):
     c.close()
     assert ParkedBuffers.bytes_parked() == 0  # switched off: nothing added
     monkeypatch.delenv("PGX_POOL_CACHE_MB")
+    WalkVerdicts.clear()
     d = VecPogema(cfg, batch=B, auto_reset=True, placement_budget_gib="half")
     d.reset(seed=3)
     whole = len(d._zone_ptrs) == 2

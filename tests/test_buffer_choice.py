@@ -141,3 +141,64 @@ def test_walk_lock_admits_one_walker_per_device():
             assert other_device is True
     with walk_lock(0) as again:
         assert again is True, "the lock is released when the walk ends"
+
+
+def test_walk_verdicts_negative_cache_logic(monkeypatch):
+    """buffers.WalkVerdicts on the CPU: a failed full-budget walk is remembered per device, only for budgets it covers; a
+    later success or clear() forgets it; PGX_WALK_NEGATIVE_CACHE=0 switches the cache off."""
+    from pogema_amd.buffers import WalkVerdicts
+    WalkVerdicts.clear()
+    w0, f0 = WalkVerdicts.walks, WalkVerdicts.failed_walks
+    assert WalkVerdicts.failed(0, 100.0) is None
+    WalkVerdicts.note_walk(0, {"spread": False, "candidates": 17, "same_zone_us": 143.0, "spacer_gib": 136.0}, 143.4)
+    v = WalkVerdicts.failed(0, 143.4)
+    assert v and v["candidates"] == 17 and v["walks"] == 1 and WalkVerdicts.failed(0, 64.0) is not None
+    assert WalkVerdicts.failed(0, 150.0) is not None, "a budget within one spacer of the failed one reaches nothing new"
+    assert WalkVerdicts.failed(0, 272.0) is None, "a clearly larger budget may walk again"
+    assert WalkVerdicts.failed(1, 10.0) is None, "verdicts are per device"
+    WalkVerdicts.note_walk(0, {"spread": False, "candidates": 30}, 272.0)
+    assert WalkVerdicts.failed(0, 272.0)["walks"] == 2
+    assert (WalkVerdicts.walks, WalkVerdicts.failed_walks) == (w0 + 2, f0 + 2)
+    monkeypatch.setenv("PGX_WALK_NEGATIVE_CACHE", "0")
+    assert WalkVerdicts.failed(0, 10.0) is None
+    monkeypatch.delenv("PGX_WALK_NEGATIVE_CACHE")
+    WalkVerdicts.note_walk(0, {"spread": True, "candidates": 2}, 143.4)   # a walk that found a zone after all
+    assert WalkVerdicts.failed(0, 10.0) is None and WalkVerdicts.failed_walks == f0 + 2
+    WalkVerdicts.note_walk(0, {"spread": False, "candidates": 1}, 8.0)
+    from pogema_amd import release_cached_buffers
+    release_cached_buffers()
+    assert WalkVerdicts.failed(0, 8.0) is None
+
+
+def test_walk_lock_file_handling(tmp_path, monkeypatch):
+    """the per-device lock file lives in a shared temp dir -- a planted symlink is not followed, another
+    tenant's read-only file still locks, an unusable file means 'not ours' under the default policy (no walk) and
+    'walk unlocked' only for an explicit request; two holders exclude each other."""
+    import stat
+    import tempfile
+    from pogema_amd import buffers
+    monkeypatch.setattr(tempfile, "gettempdir", lambda: str(tmp_path))
+    monkeypatch.setattr(buffers, "device_identity", lambda i: f"testdev{i}")
+    path = tmp_path / "pgx_zone_walk_testdev0.lock"
+    with buffers.walk_lock(0) as a:
+        assert a and path.exists() and stat.S_IMODE(path.stat().st_mode) == 0o666
+        with buffers.walk_lock(0) as b:
+            assert b is False, "a second walker on the same device must see the lock busy"
+        with buffers.walk_lock(1) as c:
+            assert c, "another device has its own lock"
+    with buffers.walk_lock(0) as again:
+        assert again
+    # read-only file of 'another tenant': flock works on a read-only descriptor
+    path.chmod(0o444)
+    with buffers.walk_lock(0) as ro:
+        assert ro
+    # a symlink planted under the predictable name is not followed
+    path.unlink()
+    victim = tmp_path / "victim"
+    victim.write_text("precious")
+    path.symlink_to(victim)
+    with buffers.walk_lock(0, wait=False) as planted:
+        assert planted is False, "unusable lock file: the default policy must not walk"
+    with buffers.walk_lock(0, wait=True) as explicit:
+        assert explicit is True, "an explicit budget walks as asked, unlocked"
+    assert victim.read_text() == "precious"

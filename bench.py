@@ -938,13 +938,14 @@ def main(argv=None):
         value = n_agent_steps / elapsed
         alg_bytes = bpas * batch * agents  # per launch (this GPU's shard)
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_file = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 with open(pmc) as f:
                     key = f"{args.workload}/{args.collision}" + ("" if args.obs_dtype == "float32" else "/" + args.obs_dtype)
-                    traffic = json.load(f).get(key, {}).get("hbm_bytes_per_launch")
+                    entry = json.load(f).get(key, {})
+                    traffic, traffic_file = entry.get("hbm_bytes_per_launch"), entry.get("source")
             except Exception:
                 traffic = None
         # BASELINE.json's metric label only for BASELINE.json's workload as the product runs it: configs[2], float32,
@@ -987,10 +988,9 @@ def main(argv=None):
             "roofline": {"bound": "hbm" if (args.buffers != 1 or alg_bytes > (200 << 20)) else "hbm (output tensor rewritten in place: largely Infinity-Cache resident)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": (None if traffic is None else
-                                            "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an "
-                                            "EARLIER run of this workload (calibrated per MI355X_MICROARCH.md; the per-round "
-                                            "summaries are profiles/rN/cfg*_pmc_summary.json) -- a looked-up figure, not measured "
-                                            "by this process"),
+                                            f"profiles/pmc_traffic.json <- {traffic_file}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                            "passes of an EARLIER run of this workload (calibrated per MI355X_MICROARCH.md) -- a "
+                                            "looked-up figure, not measured by this process"),
                          "peak_note": "8000 GB/s = HBM3E spec (MI355X_MICROARCH.md); the guide's 6.29 TB/s is a float4 COPY "
                                       "(read + write); this kernel is a write-only stream, and bare store streams reach "
                                       "6.7-7.0 TB/s on this pool (DESIGN.md section 6, roofline.box_store_stream_gbs)",
@@ -1008,7 +1008,7 @@ def main(argv=None):
                          "algorithmic_bytes_per_agent_step": bpas, "algorithmic_bytes_per_launch": alg_bytes,
                          "profile_command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-default-placement "
                                             "--no-cpu-baseline --no-extras  (the default-placement window and the secondary "
-                                            "figures launch the same kernel on other buffers / half batches; profiles/r4/README.md)"},
+                                            "figures launch the same kernel on other buffers / half batches; profiles/r5/README.md)"},
         }
         if "pipelined" in extras:
             e = extras["pipelined"]

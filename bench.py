@@ -323,6 +323,12 @@ def setup_groups(rank, world, device, try_rccl, fake_fail_ranks=()):
         dog.cancel()
 
 
+def _pinned_semantics_source():
+    """File of reference-pinned semantics defaults in force (tools/pin_reference.sh), or None = the builder's recollections."""
+    from pogema_amd.semantics import pinned_source
+    return pinned_source()
+
+
 def _walks_in_process():
     """Full-budget zone walks this process has run, over all its engines (a failed one is paid once: negative cache)."""
     from pogema_amd.buffers import WalkVerdicts
@@ -981,6 +987,7 @@ def main(argv=None):
                        "semantics": None if args.stub else {k: getattr(step.env.semantics, k) for k in
                                                                 ("soft_vertex", "soft_occupancy", "coop_reward", "bad_action",
                                                                  "lifelong_rng", "generator_rng")},
+                       "semantics_pinned_by": None if args.stub else _pinned_semantics_source(),
                        "rehearsal": bool(rehearsal),
                        "process_group": group_label if use_dist else None,
                        "launch": f"hipGraph of {args.graph} steps" if args.graph > 0 else "one pgx_step launch per step",

@@ -45,12 +45,21 @@ matrix -- so that pinning against the real package is a flip here, not a kernel 
                                  (`placing`).  One GPU thread per env (pgx_np_generate); OverflowError when an env
                                  cannot hold `num_agents` pairs.  A host-only switch: the step kernel never sees it.
 
-`PGX_SEMANTICS="soft_vertex=all_stay,coop_reward=per_agent"` overrides the defaults process-wide (one-step pinning
-of a whole test run against fixtures from the real package).
+`PGX_SEMANTICS="soft_vertex=all_stay,coop_reward=per_agent"` overrides the defaults process-wide (a whole test run
+against fixtures from the real package).
+
+PINNED DEFAULTS.  The built-in defaults above are recollections.  Once `tools/pin_reference.sh` has run against the real
+package, the positions its fixtures DEMAND are written to `pogema_amd/pinned_semantics.json` (PGX_PINNED_SEMANTICS_FILE
+names another file), and from then on they ARE the process-wide defaults (`Semantics.from_env()`, i.e. every VecPogema
+built without an explicit `semantics=`): a recollection that turns out wrong is corrected by data, with no edit here
+(the `soft_occupancy` default in particular is only as good as the memory it rests on).  Order of precedence:
+explicit `semantics=` argument > PGX_SEMANTICS > pinned file > built-in recalled literals.  `pinned_source()` says which
+file, if any, is in force; the C-ABI's numbering (0 = recalled literal) is unaffected.
 """
 from __future__ import annotations
 
 import os
+import json
 from dataclasses import dataclass
 
 LIFELONG_RNG = ("build", "numpy")
@@ -59,6 +68,36 @@ SOFT_OCCUPANCY = ("index_order", "exact")
 COOP_REWARD = ("all_solved", "per_agent")
 BAD_ACTION = ("noop", "flag")
 GENERATOR_RNG = ("build", "numpy")
+
+
+_SWITCHES = {"soft_vertex": SOFT_VERTEX, "soft_occupancy": SOFT_OCCUPANCY, "coop_reward": COOP_REWARD, "bad_action": BAD_ACTION,
+             "lifelong_rng": LIFELONG_RNG, "generator_rng": GENERATOR_RNG}
+
+
+def pinned_file() -> str:
+    return os.environ.get("PGX_PINNED_SEMANTICS_FILE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "pinned_semantics.json")
+
+
+def pinned_defaults() -> dict:
+    """{switch: value} demanded by reference fixtures (written by tools/pin_reference.sh), {} when nothing is pinned.  A
+    malformed file is an error, not something to fall through silently: the defaults of a pinned build must not depend
+    on whether a JSON file happened to parse."""
+    path = pinned_file()
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        data = json.load(f)
+    out = {}
+    for k, v in (data.get("switches") or {}).items():
+        if k not in _SWITCHES or v not in _SWITCHES[k]:
+            raise ValueError(f"{path}: {k}={v!r} is not a known semantics switch / value")
+        out[k] = v
+    return out
+
+
+def pinned_source():
+    """Path of the pinned-defaults file in force, or None (the defaults are the builder's recollections)."""
+    return pinned_file() if pinned_defaults() else None
 
 
 @dataclass(frozen=True)
@@ -78,9 +117,9 @@ class Semantics:
 
     @classmethod
     def from_env(cls) -> "Semantics":
-        """The process-wide default: built-in defaults overridden by PGX_SEMANTICS."""
+        """The process-wide default: built-in recalled literals < pinned file (reference fixtures) < PGX_SEMANTICS."""
         spec = os.environ.get("PGX_SEMANTICS", "").strip()
-        kw = {}
+        kw = pinned_defaults()
         for item in filter(None, (s.strip() for s in spec.split(","))):
             if "=" not in item:
                 raise ValueError(f"PGX_SEMANTICS entry {item!r} is not key=value")

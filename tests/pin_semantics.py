@@ -6,7 +6,7 @@
 Brute force: every combination of the step-semantics switches (soft_vertex x soft_occupancy x coop_reward x bad_action =
 2^4) is run through the literal Python oracle over every fixture -- positions, flags, rewards, observations, the occupancy
 array and the final metrics, exactly the comparison of tests/test_golden_reference.py -- and the combinations under which
-ALL fixtures pass are reported, per switch: `determined` when every passing combination agrees on it, `free` when the
+ALL fixtures pass are reported (`--write-pin FILE`: and written as the product's pinned defaults, pogema_amd/semantics.py), per switch: `determined` when every passing combination agrees on it, `free` when the
 fixtures cannot tell (e.g. bad_action: rollouts only contain valid actions -- reference_probes.json decides that one).
 Prints one JSON object; exit code 0 iff at least one combination passes.  The product's defaults
 (pogema_amd.Semantics()) are flagged when they are not among the passing combinations: that is the flip to make.
@@ -23,6 +23,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def main(argv):
+    pin_out = None
+    if "--write-pin" in argv:  # write the switch positions the fixtures demand as the product's pinned defaults
+        i = argv.index("--write-pin")
+        pin_out = argv[i + 1]
+        argv = argv[:i] + argv[i + 2:]
     if len(argv) != 2:
         sys.exit(__doc__)
     os.environ["PGX_GOLDEN_DIR"] = os.path.abspath(argv[1])
@@ -64,7 +69,15 @@ def main(argv):
         if "free" in verdict.get("bad_action", {}) and ba:
             verdict["bad_action"] = {"determined_by_probe": "flag" if ba.startswith("raises IndexError") else "noop" if ba == "noop" else ba}
     default = {n: getattr(Semantics(), n) for n in names}
-    report = {"fixtures": len(fixtures), "combinations_tried": 2 ** len(names), "passing": passing, "per_switch": verdict,
+    pin = {n: (v.get("determined") or v.get("determined_by_probe")) for n, v in verdict.items()
+           if (v.get("determined") or v.get("determined_by_probe")) in switches[n]}
+    if pin_out and passing:
+        with open(pin_out, "w") as f:
+            json.dump({"switches": pin, "fixtures": len(fixtures), "source": os.environ["PGX_GOLDEN_DIR"],
+                       "differs_from_recalled_defaults": {n: v for n, v in pin.items() if v != default[n]},
+                       "note": "written by tools/pin_reference.sh: the positions of the semantics switches that reference "
+                               "fixtures demand; pogema_amd.Semantics.from_env() uses them as the process-wide defaults"}, f, indent=1)
+    report = {"pin": pin, "pin_file": pin_out if (pin_out and passing) else None,"fixtures": len(fixtures), "combinations_tried": 2 ** len(names), "passing": passing, "per_switch": verdict,
               "product_default": default, "product_default_passes": default in passing,
               "probes": probes, "first_failure_of_failing_combinations": first_failure}
     print(json.dumps(report, indent=1))

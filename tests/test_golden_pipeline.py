@@ -115,12 +115,14 @@ def test_engine_passes_the_loaded_fixtures(fixtures):
         tgr.compare_with_fixture(engine_rollout, path)
 
 
-def _pin(out_dir, standin_semantics=""):
+def _pin(out_dir, standin_semantics="", pin_file=None):
     env = dict(os.environ, PYTHONPATH=STANDIN + os.pathsep + os.environ.get("PYTHONPATH", ""),
                PGX_STANDIN_SEMANTICS=standin_semantics)
     env.pop("PGX_SEMANTICS", None)
+    env.pop("PGX_PINNED_SEMANTICS_FILE", None)
+    extra = ["--pin-file", str(pin_file)] if pin_file else []
     p = subprocess.run(["bash", os.path.join(ROOT, "tools", "pin_reference.sh"), "--out", str(out_dir), "--geoms", "3,0",
-                        "--limit", "36"], capture_output=True, text=True, env=env, timeout=1500)
+                        "--limit", "36"] + extra, capture_output=True, text=True, env=env, timeout=1500)
     import json
     return p, json.load(open(os.path.join(str(out_dir), "pin_report.json")))
 
@@ -150,3 +152,34 @@ def test_pin_reference_script_names_the_flip_for_a_different_reference(tmp_path)
     assert sw["soft_vertex"] == {"determined": "all_stay"} and sw["soft_occupancy"] == {"determined": "exact"}
     assert sw["coop_reward"] == {"determined": "per_agent"} and sw["bad_action"] == {"determined_by_probe": "flag"}
     assert {"soft_vertex": "all_stay", "soft_occupancy": "exact", "coop_reward": "per_agent", "bad_action": "noop"} in rep["passing"]
+
+
+def test_pin_reference_script_flips_the_defaults_by_data(tmp_path, monkeypatch):
+    """ADVICE r4 / SURVEY 8(f1): with a pin file the same 'different reference' ends GREEN in one command -- the switch
+    positions its fixtures demand are written as the product's pinned defaults, the default-semantics tests then run under
+    them and pass, and `Semantics.from_env()` (what every VecPogema built without an explicit `semantics=` uses) follows
+    the file.  Precedence: PGX_SEMANTICS > pinned file > built-in recollections; a malformed file is an error."""
+    import json
+    from pogema_amd import semantics as S
+    pin = tmp_path / "pinned_semantics.json"
+    p, rep = _pin(tmp_path / "flipped", "soft_vertex_rule=all_stay,soft_occupancy=exact,coop_reward=per_agent,bad_action=flag", pin_file=pin)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert rep["product_default_passes"] is False and rep["pin_file"] == str(pin)
+    data = json.load(open(pin))
+    want = {"soft_vertex": "all_stay", "soft_occupancy": "exact", "coop_reward": "per_agent", "bad_action": "flag"}
+    assert data["switches"] == want and data["differs_from_recalled_defaults"] == want and data["fixtures"] == 36
+    assert not os.path.exists(os.path.join(ROOT, "pogema_amd", "pinned_semantics.json")), "a rehearsal must not pin the product"
+    monkeypatch.delenv("PGX_SEMANTICS", raising=False)
+    monkeypatch.delenv("PGX_PINNED_SEMANTICS_FILE", raising=False)
+    assert S.Semantics.from_env() == S.Semantics() and S.pinned_source() is None
+    monkeypatch.setenv("PGX_PINNED_SEMANTICS_FILE", str(pin))
+    sem = S.Semantics.from_env()
+    assert (sem.soft_vertex, sem.soft_occupancy, sem.coop_reward, sem.bad_action) == ("all_stay", "exact", "per_agent", "flag")
+    assert sem.lifelong_rng == "build" and S.pinned_source() == str(pin)
+    monkeypatch.setenv("PGX_SEMANTICS", "soft_occupancy=index_order")
+    assert S.Semantics.from_env().soft_occupancy == "index_order" and S.Semantics.from_env().soft_vertex == "all_stay"
+    bad = tmp_path / "bad.json"
+    bad.write_text(json.dumps({"switches": {"soft_vertex": "sometimes"}}))
+    monkeypatch.setenv("PGX_PINNED_SEMANTICS_FILE", str(bad))
+    with pytest.raises(ValueError, match="not a known semantics switch"):
+        S.Semantics.from_env()

@@ -43,8 +43,13 @@ def outside_density_of(obstacles):
 
 
 def _oracle_semantics(semantics):
-    """pogema_amd.Semantics (or None = defaults) -> the oracles' keyword arguments."""
-    return {} if semantics is None else semantics.oracle_kwargs()
+    """pogema_amd.Semantics -> the oracles' keyword arguments.  None = the PRODUCT's process-wide default
+    (`Semantics.from_env()`: recalled literals < pinned file < PGX_SEMANTICS): the checker runs under the semantics the
+    engine it checks runs under, also after reference fixtures have pinned another default."""
+    if semantics is None:
+        from pogema_amd.semantics import Semantics
+        semantics = Semantics.from_env()
+    return semantics.oracle_kwargs()
 
 
 def oracle_rollout(obstacles, agents, targets, actions, *, obs_radius, collision_system, on_target,

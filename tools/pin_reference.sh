@@ -4,6 +4,9 @@
 #     tools/pin_reference.sh                 fixtures -> tests/golden/, then the checks below
 #     tools/pin_reference.sh --out DIR       fixtures somewhere else (the stand-in rehearsal of tests/test_golden_pipeline.py)
 #     tools/pin_reference.sh --limit N       first N cases only;   --geoms 0,3   only these geometries of gen_golden.py
+#     tools/pin_reference.sh --pin-file F    where the demanded switch positions are written as the product's pinned defaults
+#                                            (default: pogema_amd/pinned_semantics.json for a run into tests/golden, nowhere
+#                                            for --out elsewhere)
 #
 #   1. tools/gen_golden.py            drives the importable `pogema` over the seeded cases: reference_*.npz (inputs, expected
 #                                      outputs, the occupancy array, final metrics) + reference_probes.json
@@ -11,25 +14,35 @@
 #                                      those fixtures and prints which combination(s) make ALL of them pass
 #   3. pytest tests/test_golden_reference.py -m "not gpu"     oracle + numpy-stream generator against every fixture under
 #                                      the product's DEFAULT semantics (on a GPU box add:  -m gpu  for the engine)
-# Exit code: 0 iff a passing combination exists AND the default-semantics tests pass.  When (2) passes but (3) fails, the
-# report names the switch to flip (pogema_amd/semantics.py defaults, or PGX_SEMANTICS=... for one run).
+# Between (2) and (3) the positions the fixtures demand become the product's PINNED DEFAULTS (pogema_amd/semantics.py reads
+# the pin file): a recollection the real package contradicts is flipped by data, not by an edit, and (3) then runs under
+# what the reference actually does.  Exit code: 0 iff a passing combination exists AND the tests of (3) pass.  Without a pin
+# file (--out elsewhere and no --pin-file) (3) runs under the built-in recalled defaults and the report names the flips.
 set -u
 cd "$(dirname "$0")/.." || exit 1
-OUT=tests/golden; LIMIT=0; GEOMS=""
+OUT=tests/golden; LIMIT=0; GEOMS=""; PINFILE=""; PINSET=0
 while [ $# -gt 0 ]; do
   case "$1" in
     --out) OUT="$2"; shift 2;;
     --limit) LIMIT="$2"; shift 2;;
     --geoms) GEOMS="$2"; shift 2;;
+    --pin-file) PINFILE="$2"; PINSET=1; shift 2;;
     *) echo "unknown argument $1" >&2; exit 2;;
   esac
 done
+[ "$PINSET" -eq 0 ] && [ "$OUT" = tests/golden ] && PINFILE=pogema_amd/pinned_semantics.json
 mkdir -p "$OUT"
 echo "== 1/3 generating fixtures into $OUT"
 python3 tools/gen_golden.py --out "$OUT" --limit "$LIMIT" --geoms "$GEOMS" || exit 1
 echo "== 2/3 which semantics do the fixtures demand?"
-python3 tests/pin_semantics.py "$OUT" | tee "$OUT/pin_report.json"
-PIN=${PIPESTATUS[0]}
+if [ -n "$PINFILE" ]; then
+  python3 tests/pin_semantics.py "$OUT" --write-pin "$PINFILE" | tee "$OUT/pin_report.json"
+  PIN=${PIPESTATUS[0]}
+  [ -f "$PINFILE" ] && export PGX_PINNED_SEMANTICS_FILE="$(cd "$(dirname "$PINFILE")" && pwd)/$(basename "$PINFILE")" && echo "== pinned defaults written to $PINFILE"
+else
+  python3 tests/pin_semantics.py "$OUT" | tee "$OUT/pin_report.json"
+  PIN=${PIPESTATUS[0]}
+fi
 echo "== 3/3 oracle + generator against the fixtures under the product's default semantics"
 PGX_GOLDEN_DIR="$(cd "$OUT" && pwd)" python3 -m pytest tests/test_golden_reference.py -q -m "not gpu" -p no:cacheprovider
 T=$?

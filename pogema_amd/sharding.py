@@ -284,6 +284,7 @@ class HostGather:
         slot = q % self.slots
         if q >= self.slots:  # the slot still holds ticket q - slots: rank dst must have released it
             old = q - self.slots
+            self._retire(old)
             if self.rank == self.dst or self._ctr is None:
                 if old > self._done - 1:
                     raise ValueError(f"HostGather: start() number {q} would overwrite ticket {old}, whose views are still "
@@ -333,6 +334,16 @@ class HostGather:
         self._pump()
         return q
 
+    def _retire(self, old: int):
+        """This rank's OWN copies of tickets <= `old` have landed (normally long since: a no-op) -- required before the
+        slot and the snapshot buffer of ticket `old` are rewritten, also on a rank that never called finish() for it."""
+        if self._pending and self._pending[0][0] <= old:
+            self._pump(upto=old)
+        for k in [k for k in self._issued if k <= old]:
+            done, _sources = self._issued.pop(k)
+            if done is not None:
+                done.synchronize()
+
     def _pump(self, upto: int = -1):
         """Issues the copies of every pending ticket whose producer has finished (tickets <= `upto`: waits for it)."""
         while self._pending:
@@ -360,6 +371,8 @@ class HostGather:
         because that slot's previous ticket has been finished by then (start() checks).  Views are built once per slot
         and per source pair: the per-step cost is one dictionary look-up and the fused copy."""
         slot = self._seq % self.slots
+        if self._seq >= self.slots:
+            self._retire(self._seq - self.slots)  # the D2H copy that read this slot's snapshot buffer last time is done
         if not hasattr(self, "_snaps"):
             self._snaps, self._snap_src = {}, {}
         skey = (flags.data_ptr(), values.data_ptr(), flags.numel(), values.numel())

@@ -339,12 +339,18 @@ def gpu_identity(dev_index):
     """What tells this rank's GPU apart from its neighbours in the line: HIP uuid (= the unique_id of sysfs / KFD) and
     PCI address."""
     import torch
-    out = {"uuid": None, "pci": None, "name": None, "total_gib": None}
+    out = {"uuid": None, "unique_id": None, "pci": None, "name": None, "total_gib": None}
     try:
         pr = torch.cuda.get_device_properties(dev_index)
         out.update(name=pr.name, total_gib=round(pr.total_memory / float(1 << 30), 1))
         u = getattr(pr, "uuid", None)
         out["uuid"] = str(u) if u is not None else None
+        try:  # ROCm fills the uuid with the ASCII of the 16 hex digits that sysfs / KFD / rocm-smi call unique_id (`box` field)
+            text = bytes.fromhex(out["uuid"].replace("-", "")).decode("ascii")
+            if len(text) == 16 and all(c in "0123456789abcdefABCDEF" for c in text):
+                out["unique_id"] = "0x" + text.lower()
+        except (ValueError, AttributeError):
+            pass
         if hasattr(pr, "pci_bus_id"):
             out["pci"] = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{getattr(pr, 'pci_device_id', 0):02x}"
     except Exception:  # noqa: BLE001

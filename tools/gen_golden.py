@@ -67,6 +67,41 @@ def greedy_actions(obstacles, agents_xy, targets_xy, rng):
     return acts
 
 
+def _unpadded(grid, r, method, attr):
+    """Public accessor first (`Grid.get_*_xy(ignore_borders=True)`), else the raw padded attribute minus the border --
+    so that a release whose accessor is named or shaped differently still yields fixtures."""
+    fn = getattr(grid, method, None)
+    if callable(fn):
+        try:
+            return np.asarray(fn(ignore_borders=True))
+        except TypeError:
+            pass
+    raw = np.asarray(getattr(grid, attr))
+    return raw[r:-r, r:-r] if raw.ndim == 2 and attr == "obstacles" else raw - r
+
+
+def obstacles_of(grid, r):
+    return (_unpadded(grid, r, "get_obstacles", "obstacles") != 0).astype(np.uint8)
+
+
+def agents_of(grid, r):
+    return np.asarray(_unpadded(grid, r, "get_agents_xy", "positions_xy"), dtype=np.int32)
+
+
+def targets_of(grid, r):
+    return np.asarray(_unpadded(grid, r, "get_targets_xy", "finishes_xy"), dtype=np.int32)
+
+
+def grid_of(env):
+    """The Grid behind whatever wrappers `pogema_v0` stacked (looked up again after every reset: lifelong environments
+    re-create it)."""
+    base = env.unwrapped if hasattr(env, "unwrapped") else env
+    seen = 0
+    while not hasattr(base, "grid") and hasattr(base, "env") and seen < 16:
+        base, seen = base.env, seen + 1
+    return base.grid
+
+
 def main():
     ap = argparse.ArgumentParser()
     golden = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
@@ -92,70 +127,86 @@ def main():
     if args.geoms:
         geoms = [geoms[int(i)] for i in args.geoms.split(",")]
     n = 0
+    failures = []  # a case the package refuses (unknown option in this release, unplaceable instance ...) must not cost the rest
     for g, cs, ot, seed in itertools.product(geoms, ("priority", "block_both", "soft"),
                                              ("finish", "restart", "nothing"), (0, 1, 2)):
         if args.limit and n >= args.limit:
             break
-        gc = GridConfig(seed=seed, collision_system=cs, on_target=ot, max_episode_steps=32, **g)
-        env = pogema_v0(gc)
-        obs, _ = env.reset(seed=seed)
-        grid = env.unwrapped.grid if hasattr(env, "unwrapped") else env.grid
-        r = gc.obs_radius
-        obstacles = np.asarray(grid.get_obstacles(ignore_borders=True), dtype=np.uint8)
-        agents0 = np.asarray(grid.get_agents_xy(ignore_borders=True), dtype=np.int32)
-        targets0 = np.asarray(grid.get_targets_xy(ignore_borders=True), dtype=np.int32)
-        rng = np.random.default_rng(1000 + seed)
-        T = gc.max_episode_steps
-        actions = rng.integers(0, 5, size=(T, gc.num_agents))
-        greedy = seed == 2  # one seed in three is driven towards the goals (early termination, goal-side conflicts)
-        rec = dict(obs0=np.stack(obs), obs=[], rewards=[], terminated=[], truncated=[], is_active=[], agents_xy=[],
-                   targets_xy=[])
-        has_positions = hasattr(grid, "positions")  # the occupancy array (padded), `Grid.positions` upstream
+        case = f"{g['size']}x{g['num_agents']}_{cs}_{ot}_s{seed}"
+        try:
+            n += one_case(GridConfig, pogema_v0, g, cs, ot, seed, out_dir)
+        except Exception as exc:  # noqa: BLE001
+            failures.append({"case": case, "error": repr(exc)})
+            print(f"case {case} FAILED: {exc!r}", file=sys.stderr)
+    write_probes(pogema, GridConfig, pogema_v0, out_dir, failures)
+    print(f"wrote {n} fixtures to {out_dir}" + (f"; {len(failures)} case(s) failed (reference_probes.json)" if failures else ""))
+    if n == 0:
+        sys.exit("no fixture could be generated")
+
+
+def one_case(GridConfig, pogema_v0, g, cs, ot, seed, out_dir):
+    gc = GridConfig(seed=seed, collision_system=cs, on_target=ot, max_episode_steps=32, **g)
+    env = pogema_v0(gc)
+    obs, _ = env.reset(seed=seed)
+    grid = grid_of(env)
+    r = gc.obs_radius
+    obstacles = obstacles_of(grid, r)
+    agents0 = agents_of(grid, r)
+    targets0 = targets_of(grid, r)
+    rng = np.random.default_rng(1000 + seed)
+    T = gc.max_episode_steps
+    actions = rng.integers(0, 5, size=(T, gc.num_agents))
+    greedy = seed == 2  # one seed in three is driven towards the goals (early termination, goal-side conflicts)
+    rec = dict(obs0=np.stack(obs), obs=[], rewards=[], terminated=[], truncated=[], is_active=[], agents_xy=[],
+               targets_xy=[])
+    has_positions = hasattr(grid, "positions")  # the occupancy array (padded), `Grid.positions` upstream
+    if has_positions:
+        rec["positions0"] = np.asarray(grid.positions, dtype=np.uint8).copy()
+        rec["positions"] = []
+    metrics = None
+    for t in range(T):
+        if greedy:
+            actions[t] = greedy_actions(obstacles, agents_of(grid, r), targets_of(grid, r), rng)
+        obs, rew, term, trunc, infos = env.step(actions[t].tolist())
+        rec["obs"].append(np.stack(obs))
+        rec["rewards"].append(rew)
+        rec["terminated"].append(term)
+        rec["truncated"].append(trunc)
+        rec["is_active"].append([i.get("is_active", True) for i in infos])
+        rec["agents_xy"].append(agents_of(grid, r))
+        rec["targets_xy"].append(targets_of(grid, r))
         if has_positions:
-            rec["positions0"] = np.asarray(grid.positions, dtype=np.uint8).copy()
-            rec["positions"] = []
-        metrics = None
-        for t in range(T):
-            if greedy:
-                actions[t] = greedy_actions(obstacles, grid.get_agents_xy(ignore_borders=True),
-                                            grid.get_targets_xy(ignore_borders=True), rng)
-            obs, rew, term, trunc, infos = env.step(actions[t].tolist())
-            rec["obs"].append(np.stack(obs))
-            rec["rewards"].append(rew)
-            rec["terminated"].append(term)
-            rec["truncated"].append(trunc)
-            rec["is_active"].append([i.get("is_active", True) for i in infos])
-            rec["agents_xy"].append(grid.get_agents_xy(ignore_borders=True))
-            rec["targets_xy"].append(grid.get_targets_xy(ignore_borders=True))
-            if has_positions:
-                rec["positions"].append(np.asarray(grid.positions, dtype=np.uint8).copy())
-            if isinstance(infos[0], dict) and isinstance(infos[0].get("metrics"), dict):
-                metrics = (t, infos[0]["metrics"])
-            if all(term) or all(trunc):
-                actions = actions[:t + 1]
-                break
-        extra = {}
-        if metrics is not None:  # names as one '|'-joined string (no pickles in the fixtures), values in the same order
-            names = sorted(metrics[1])
-            extra = dict(metrics_step=metrics[0], metrics_names="|".join(names),
-                         metrics_values=np.asarray([float(metrics[1][k]) for k in names], dtype=np.float64))
-        name = f"reference_{g['size']}x{g['num_agents']}_{cs}_{ot}_s{seed}.npz"
-        np.savez_compressed(os.path.join(out_dir, name), obstacles=obstacles, agents_xy0=agents0, targets_xy0=targets0,
-                            actions=actions, obs_radius=r, collision_system=cs, on_target=ot,
-                            max_episode_steps=gc.max_episode_steps, grid_seed=seed, density=gc.density, **extra,
-                            **{k: np.asarray(v) for k, v in rec.items()})
-        n += 1
+            rec["positions"].append(np.asarray(grid.positions, dtype=np.uint8).copy())
+        if isinstance(infos[0], dict) and isinstance(infos[0].get("metrics"), dict):
+            metrics = (t, infos[0]["metrics"])
+        if all(term) or all(trunc):
+            actions = actions[:t + 1]
+            break
+    extra = {}
+    if metrics is not None:  # names as one '|'-joined string (no pickles in the fixtures), values in the same order
+        names = sorted(metrics[1])
+        extra = dict(metrics_step=metrics[0], metrics_names="|".join(names),
+                     metrics_values=np.asarray([float(metrics[1][k]) for k in names], dtype=np.float64))
+    name = f"reference_{g['size']}x{g['num_agents']}_{cs}_{ot}_s{seed}.npz"
+    np.savez_compressed(os.path.join(out_dir, name), obstacles=obstacles, agents_xy0=agents0, targets_xy0=targets0,
+                        actions=actions, obs_radius=r, collision_system=cs, on_target=ot,
+                        max_episode_steps=gc.max_episode_steps, grid_seed=seed, density=gc.density, **extra,
+                        **{k: np.asarray(v) for k, v in rec.items()})
+    return 1
+
+
+def write_probes(pogema, GridConfig, pogema_v0, out_dir, failures):
     # ---- probes: behaviour no rollout of valid actions shows -------------------------------------------------
     probes = {"package": getattr(pogema, "__name__", "pogema"), "version": str(getattr(pogema, "__version__", "?")),
-              "standin": bool(getattr(pogema, "__standin__", False))}
+              "standin": bool(getattr(pogema, "__standin__", False)), "failed_cases": failures}
     try:  # docs/SPEC.md Q7: an action outside 0..4
         env = pogema_v0(GridConfig(seed=0, size=8, num_agents=2, obs_radius=2, density=0.1))
         env.reset(seed=0)
-        g0 = env.unwrapped.grid if hasattr(env, "unwrapped") else env.grid
-        before = [list(map(int, p)) for p in g0.get_agents_xy(ignore_borders=True)]
+        g0 = grid_of(env)
+        before = [list(map(int, p)) for p in agents_of(g0, 2)]
         try:
             env.step([7, 0])
-            after = [list(map(int, p)) for p in g0.get_agents_xy(ignore_borders=True)]
+            after = [list(map(int, p)) for p in agents_of(g0, 2)]
             probes["bad_action"] = "noop" if after == before else f"moved {before} -> {after}"
         except Exception as exc:  # noqa: BLE001
             probes["bad_action"] = f"raises {type(exc).__name__}"
@@ -172,7 +223,6 @@ def main():
         probes["grid_config_defaults"] = f"probe failed: {exc!r}"
     with open(os.path.join(out_dir, "reference_probes.json"), "w") as f:
         json.dump(probes, f, indent=1, default=str)
-    print(f"wrote {n} fixtures to {out_dir}")
 
 
 if __name__ == "__main__":

@@ -34,7 +34,8 @@ def main(argv):
     import test_golden_reference as tgr
     from pogema_amd.semantics import BAD_ACTION, COOP_REWARD, SOFT_OCCUPANCY, SOFT_VERTEX, Semantics
     from util import oracle_rollout
-    fixtures = sorted(glob.glob(os.path.join(os.environ["PGX_GOLDEN_DIR"], "reference_*.npz")))
+    fixtures = [p for p in sorted(glob.glob(os.path.join(os.environ["PGX_GOLDEN_DIR"], "reference_*.npz")))
+                if not os.path.basename(p).startswith("reference_grid_")]  # (grid-layer fixtures carry no envs.py semantics)
     if not fixtures:
         sys.exit(f"no reference_*.npz under {argv[1]}")
     switches = {"soft_vertex": SOFT_VERTEX, "soft_occupancy": SOFT_OCCUPANCY, "coop_reward": COOP_REWARD, "bad_action": BAD_ACTION}

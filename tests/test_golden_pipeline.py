@@ -183,3 +183,59 @@ def test_pin_reference_script_flips_the_defaults_by_data(tmp_path, monkeypatch):
     monkeypatch.setenv("PGX_PINNED_SEMANTICS_FILE", str(bad))
     with pytest.raises(ValueError, match="not a known semantics switch"):
         S.Semantics.from_env()
+
+
+STANDIN_SRC = os.path.join(ROOT, "tests", "standin_pogema_src")
+
+
+def _grid_fixtures(tmp_path):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_golden_grid.py"), "--ref", STANDIN_SRC, "--out", str(tmp_path),
+                        "--limit", "10"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+    files = sorted(glob.glob(os.path.join(str(tmp_path), "reference_grid_*.npz")))
+    assert len(files) == 10
+    return files
+
+
+def test_grid_layer_fixtures_without_importing_the_package(tmp_path):
+    """a source tree whose `pogema/__init__.py` cannot be imported (no gymnasium) still yields fixtures
+    of the grid layer -- tools/gen_golden_grid.py loads grid_config / generator / grid under a bare `pogema` namespace.
+    The stand-in tree's __init__ raises ImportError, so the rehearsal proves the bypass; the fixtures pin rows A1-A3 and
+    A9-A11 (oracle), the border ring, and the numpy-stream instance generator."""
+    with pytest.raises(ImportError):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("pogema_standin_src_init", os.path.join(STANDIN_SRC, "pogema", "__init__.py"))
+        spec.loader.exec_module(importlib.util.module_from_spec(spec))
+    files = _grid_fixtures(tmp_path)
+    from pogema_amd.nprng import np_generate_host
+    for path in files:
+        tgr.compare_grid_fixture(oracle_rollout, path)
+        tgr.compare_border_with_grid_fixture(path)
+        assert tgr.compare_generator_with_fixture(np_generate_host, path)
+    # a corrupted fixture is caught: one agent one cell off after the third step
+    z = dict(np.load(files[3], allow_pickle=False))
+    z["agents_xy"] = z["agents_xy"].copy()
+    z["agents_xy"][2, 0, 0] += 1
+    bad = tmp_path / "reference_grid_bad.npz"
+    np.savez_compressed(bad, **z)
+    with pytest.raises(AssertionError):
+        tgr.compare_grid_fixture(oracle_rollout, str(bad))
+    # the generator refuses to put stand-in output into tests/golden, and says what is missing for a tree without grid.py
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_golden_grid.py"), "--ref", STANDIN_SRC], capture_output=True, text=True)
+    assert p.returncode != 0 and "STAND-IN" in p.stderr
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_golden_grid.py"), "--ref", str(tmp_path), "--out", str(tmp_path)],
+                       capture_output=True, text=True)
+    assert p.returncode != 0 and "not found" in p.stderr
+
+
+def test_pin_reference_script_grid_only_mode(tmp_path):
+    p = subprocess.run(["bash", os.path.join(ROOT, "tools", "pin_reference.sh"), "--grid-only", "--ref", STANDIN_SRC, "--out",
+                        str(tmp_path / "g"), "--limit", "6"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-1000:]
+    assert "grid-layer tests rc=0" in p.stdout and "12 passed" in p.stdout  # 6 fixtures x (oracle + border ring, generator); engine: -m gpu
+
+
+@pytest.mark.gpu
+def test_engine_passes_the_grid_layer_fixtures(tmp_path):
+    for path in _grid_fixtures(tmp_path):
+        tgr.compare_grid_fixture(engine_rollout, path)

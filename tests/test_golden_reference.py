@@ -24,7 +24,8 @@ from util import assert_rollouts_equal, engine_rollout, oracle_rollout
 
 # PGX_GOLDEN_DIR: fixtures somewhere else than tests/golden (tools/pin_reference.sh --out DIR; the stand-in rehearsal)
 GOLDEN_DIR = os.environ.get("PGX_GOLDEN_DIR") or os.path.join(os.path.dirname(__file__), "golden")
-FIXTURES = sorted(glob.glob(os.path.join(GOLDEN_DIR, "reference_*.npz")))
+GRID_FIXTURES = sorted(glob.glob(os.path.join(GOLDEN_DIR, "reference_grid_*.npz")))  # tools/gen_golden_grid.py: the grid layer alone
+FIXTURES = [p for p in sorted(glob.glob(os.path.join(GOLDEN_DIR, "reference_*.npz"))) if p not in GRID_FIXTURES]
 KEYS = ("obs0", "obs", "rewards", "terminated", "truncated", "is_active", "agents_xy", "targets_xy")
 METRIC_NAMES = ("ISR", "CSR", "ep_length", "SoC", "makespan", "avg_throughput")  # column order of the engine's metrics
 
@@ -106,3 +107,56 @@ def test_oracle_matches_reference_fixture(path):
 @pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p) for p in FIXTURES])
 def test_engine_matches_reference_fixture(path):
     compare_with_fixture(engine_rollout, path)
+
+
+# ---- fixtures of the grid layer alone (tools/gen_golden_grid.py: upstream's Grid driven without pogema/__init__.py) --------
+def compare_grid_fixture(run, path):
+    """A scripted episode of `grid.move(agent, action)` in index order IS collision_system='priority'; with
+    on_target='nothing' nobody is ever hidden and no target changes, so positions, the occupancy array and all three
+    observation planes of every agent after every step must match."""
+    z = np.load(path, allow_pickle=False)
+    T = z["actions"].shape[0]
+    ref = {"obs0": z["obs0"][None], "obs": z["obs"][:, None], "agents_xy": z["agents_xy"][:, None]}
+    extra = {}
+    if "positions" in z.files:
+        ref["occupancy0"] = z["positions0"][None].astype(np.uint8)
+        ref["occupancy"] = z["positions"][:, None].astype(np.uint8)
+        if run is engine_rollout:
+            extra["with_occupancy"] = True
+    got = run(z["obstacles"][None], z["agents_xy0"][None], z["targets_xy0"][None], z["actions"][:, None, :],
+              obs_radius=int(z["obs_radius"]), collision_system="priority", on_target="nothing", max_episode_steps=T + 8,
+              auto_reset=False, **extra)
+    assert_rollouts_equal(ref, {k: v for k, v in got.items() if k in ref}, os.path.basename(path))
+
+
+def compare_border_with_grid_fixture(path):
+    """the padded obstacle array upstream's `Grid.__init__` builds (border ring at offset r - 1, free outside)
+    against the oracle's."""
+    from oracle.pogema_oracle import Grid
+    z = np.load(path, allow_pickle=False)
+    g = Grid(z["obstacles"], z["agents_xy0"], z["targets_xy0"], int(z["obs_radius"]))
+    np.testing.assert_array_equal((g.obstacles != 0).astype(np.uint8), z["padded_obstacles"], err_msg=os.path.basename(path))
+
+
+_no_grid = pytest.mark.skipif(not GRID_FIXTURES, reason="no grid-layer fixtures: the reference's source is not available in this container")
+
+
+@_no_grid
+@pytest.mark.parametrize("path", GRID_FIXTURES, ids=[os.path.basename(p) for p in GRID_FIXTURES])
+def test_oracle_matches_grid_fixture(path):
+    compare_grid_fixture(oracle_rollout, path)
+    compare_border_with_grid_fixture(path)
+
+
+@_no_grid
+@pytest.mark.parametrize("path", GRID_FIXTURES, ids=[os.path.basename(p) for p in GRID_FIXTURES])
+def test_numpy_generator_matches_grid_fixture(path):
+    from pogema_amd.nprng import np_generate_host
+    assert compare_generator_with_fixture(np_generate_host, path)
+
+
+@pytest.mark.gpu
+@_no_grid
+@pytest.mark.parametrize("path", GRID_FIXTURES, ids=[os.path.basename(p) for p in GRID_FIXTURES])
+def test_engine_matches_grid_fixture(path):
+    compare_grid_fixture(engine_rollout, path)

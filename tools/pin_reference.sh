@@ -4,6 +4,10 @@
 #     tools/pin_reference.sh                 fixtures -> tests/golden/, then the checks below
 #     tools/pin_reference.sh --out DIR       fixtures somewhere else (the stand-in rehearsal of tests/test_golden_pipeline.py)
 #     tools/pin_reference.sh --limit N       first N cases only;   --geoms 0,3   only these geometries of gen_golden.py
+#     tools/pin_reference.sh --grid-only --ref DIR   the reference's SOURCE is there but `import pogema` fails (no gymnasium):
+#                                            tools/gen_golden_grid.py drives upstream's grid layer alone (Grid, generator;
+#                                            rows A1-A3, A9-A11 and the numpy-stream generator) -> reference_grid_*.npz,
+#                                            then the grid tests of tests/test_golden_reference.py; envs.py stays unpinned
 #     tools/pin_reference.sh --pin-file F    where the demanded switch positions are written as the product's pinned defaults
 #                                            (default: pogema_amd/pinned_semantics.json for a run into tests/golden, nowhere
 #                                            for --out elsewhere)
@@ -20,18 +24,29 @@
 # file (--out elsewhere and no --pin-file) (3) runs under the built-in recalled defaults and the report names the flips.
 set -u
 cd "$(dirname "$0")/.." || exit 1
-OUT=tests/golden; LIMIT=0; GEOMS=""; PINFILE=""; PINSET=0
+OUT=tests/golden; LIMIT=0; GEOMS=""; PINFILE=""; PINSET=0; GRIDONLY=0; REF=/root/reference
 while [ $# -gt 0 ]; do
   case "$1" in
     --out) OUT="$2"; shift 2;;
     --limit) LIMIT="$2"; shift 2;;
     --geoms) GEOMS="$2"; shift 2;;
     --pin-file) PINFILE="$2"; PINSET=1; shift 2;;
+    --grid-only) GRIDONLY=1; shift;;
+    --ref) REF="$2"; shift 2;;
     *) echo "unknown argument $1" >&2; exit 2;;
   esac
 done
 [ "$PINSET" -eq 0 ] && [ "$OUT" = tests/golden ] && PINFILE=pogema_amd/pinned_semantics.json
 mkdir -p "$OUT"
+if [ "$GRIDONLY" -eq 1 ]; then
+  echo "== 1/2 grid-layer fixtures from the source tree under $REF into $OUT"
+  python3 tools/gen_golden_grid.py --ref "$REF" --out "$OUT" --limit "$LIMIT" || exit 1
+  echo "== 2/2 oracle + numpy-stream generator against the grid-layer fixtures"
+  PGX_GOLDEN_DIR="$(cd "$OUT" && pwd)" python3 -m pytest tests/test_golden_reference.py -q -m "not gpu" -k grid -p no:cacheprovider
+  T=$?
+  echo "== grid-layer tests rc=$T (rows A1-A3, A9-A11 and the instance generator; envs.py -- rewards, flags, block_both, soft, lifelong -- needs an importable package)"
+  exit $T
+fi
 echo "== 1/3 generating fixtures into $OUT"
 python3 tools/gen_golden.py --out "$OUT" --limit "$LIMIT" --geoms "$GEOMS" || exit 1
 echo "== 2/3 which semantics do the fixtures demand?"

@@ -67,7 +67,10 @@ for wl in wls:
             with open(bench) as f:
                 summary["bench_line"] = json.loads(f.readline())
             pl = (summary["bench_line"].get("roofline") or {}).get("placement") or {}
-            summary["placement_tier"] = "zone" if pl.get("spread") else "nozone"
+            # "nozone" only after a walk that really went far and found nothing; short launches (< 128 MiB: no walk) and
+            # walks that stopped early are "unplaced"
+            summary["placement_tier"] = ("zone" if pl.get("spread") else
+                                         "nozone" if (pl.get("walk_candidates") or 0) >= 8 else "unplaced")
         except Exception:
             pass
     # write-request stall counters of the step kernel (one pass, product placement): sums over the TCC channel instances

@@ -40,7 +40,8 @@ def _check_host_gather(line, world):
     assert "error" not in hg, hg
     assert hg["mode"] == ("shared segment" if world > 1 else "private staging")
     assert hg["with_gather_ms_per_step"] > 0 and hg["loop_ms_per_step"] > 0 and hg["bytes_per_step_per_rank"] > 0
-    assert hg["obs_d2h_equal"] is True and 5 < hg["obs_d2h_gbs"] < 70
+    # (one rank: 53-57 GB/s; eight ranks sharing ONE device, one set of copy engines and one PCIe link: 6.7 GB/s each seen)
+    assert hg["obs_d2h_equal"] is True and (5 if world == 1 else 0.3) < hg["obs_d2h_gbs"] < 70
 
 
 def _env(**extra):

@@ -28,7 +28,7 @@ def _check_per_rank(line, world):
         assert e["kernel_ms"] > 0 and e["envs"] > 0 and 0 < e["frac"] < 1.0
         assert e["gpu"]["uuid"] or e["gpu"]["pci"], "the record must say WHICH GPU"
         assert isinstance(e["spread"], bool) and "walk_candidates" in e and "policy" in e
-        assert e["box_store_stream_gbs"] is None or e["box_store_stream_gbs"] > 1000
+        assert e["box_store_stream_gbs"] is None or e["box_store_stream_gbs"] > 100  # (a sanity bound: ranks may share the device)
         if e["box_store_stream_gbs"]:
             assert e["frac_of_box_store_stream"] == pytest.approx(e["achieved_gbs"] / e["box_store_stream_gbs"])
     assert [e["kernel_ms"] for e in pr] == pytest.approx(line["roofline"]["kernel_ms_per_rank"])

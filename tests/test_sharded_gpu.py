@@ -156,6 +156,36 @@ def _rank(rank, world, port, tmpdir):
         got = {k: gather_to_host(v, GB) for k, v in (("obs0", obs0), ("obs", obs), ("rew_sum", rew_sum), ("trunc", trunc),
                                                      ("xy", st["agents_xy"]), ("tgt", st["targets_xy"]),
                                                      ("elapsed", st["elapsed"]), ("map", env._initial[0]))}
+        # the same with two steps in flight, uneven host speeds and only the small outputs (the form bench.py times): every
+        # ticket's host tensors must be exactly that step's -- snapshot buffers, slots and recycled output sets are all reused
+        import random
+        import time
+        rnd = random.Random(100 + rank)
+        hg2 = HostGather(step_output_fields(env), GB, slots=4)
+        pend, want = [], {}
+        for t in range(T, T + 30):
+            res = env.step(mine[t % T])
+            tk = start_step_gather(hg2, res)
+            want[tk] = {"rewards": gather_to_host(res[1], GB), "terminated": gather_to_host(res[2], GB),
+                        "is_active": gather_to_host(res[4]["is_active"], GB),
+                        "episode_done": gather_to_host(res[4]["episode_done"], GB), "metrics": gather_to_host(res[4]["metrics"], GB)}
+            del res
+            pend.append(tk)
+            if rnd.random() < 0.3:
+                time.sleep(0.002 * (1 + rank))
+            if len(pend) > 2:
+                k = pend.pop(0)
+                got_k = hg2.finish(k)
+                if rank == 0:
+                    for name, w in want.pop(k).items():
+                        assert torch.equal(got_k[name], w), f"HostGather (two steps in flight) ticket {k}: {name}"
+        while pend:
+            k = pend.pop(0)
+            got_k = hg2.finish(k)
+            if rank == 0:
+                for name, w in want.pop(k).items():
+                    assert torch.equal(got_k[name], w), f"HostGather (two steps in flight) ticket {k}: {name}"
+        hg2.close()
         env.close()
         if rank == 0:
             # the unsharded engine on the same device ...

@@ -36,6 +36,10 @@ def choose_buffers(zone_us, plain_us, n, margin=0.98):
 
 
 class PlacementMixin:
+    """Buffer placement of a VecPogema (see the module docstring).  Expects of the class it is mixed into: `_handle`, `_lib`,
+    `device`, `device_index`, `obs_shape`, `obs_dtype`, `batch`, `num_agents`, `placement_probe`, `placement_budget_gib`,
+    `single_buffer`, `_has_state()`, `_stream()`; maintains `placement`, `_zone_ptrs`, `_recycler`, `_rollout_pools`."""
+
     def _shelf_key(self):
         return (self.device_index, tuple(self.obs_shape), self.obs_dtype)
 

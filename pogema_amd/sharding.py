@@ -265,6 +265,8 @@ class HostGather:
             polls += 1
             if polls % 64 == 0:
                 os.sched_yield()
+                if polls > 20000:       # a long wait (a slow peer, not the normal microseconds): stop burning the core
+                    time.sleep(50e-6)
                 if time.monotonic() - t0 > self.timeout_s:
                     raise RuntimeError(f"HostGather rank {self.rank}: waited {self.timeout_s:.0f} s for {what}")
 

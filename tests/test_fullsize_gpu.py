@@ -84,6 +84,24 @@ def test_bench_geometry_is_what_design_md_says():
         assert (g["lanes_per_env"], g["envs_per_wave"], g["waves"], g["p16"], g["store_policy"]) == shape, (workload, g)
 
 
+def test_geometry_reports_the_store_flavour_as_executed():
+    """the generic funnels of the lighter observation formats know plain and nontemporal stores only; where the
+    launch shape asks for sc1 (single-wave kernels) they run -- and pgx_get_geometry now reports -- plain stores.  float32
+    and the 16-bit formats on the fast row walk (window >= 7 cells, 16-bit row masks) honour all three flavours."""
+    import torch
+    from pogema_amd import GridConfig, VecPogema
+    want = {  # (obs_radius, dtype) -> store_policy of a 16-agent single-wave launch (the shape asks for sc1 = 2)
+        (5, torch.float32): 2, (5, torch.bfloat16): 2, (5, torch.float16): 2, (5, torch.uint8): 0,
+        (2, torch.bfloat16): 0,   # window of 5 cells: the generic 16-bit funnel
+        (9, torch.float32): 2, (9, torch.float16): 0, (9, torch.uint8): 0,   # window of 19 cells: beyond the 16-bit row masks
+    }
+    for (r, dt), policy in want.items():
+        env = VecPogema(GridConfig(size=24, num_agents=16, obs_radius=r, density=0.2, seed=1), batch=64, obs_dtype=dt)
+        g = env.geometry()
+        assert g["multi_wave"] == 0 and g["store_policy"] == policy, (r, dt, g)
+        env.close()
+
+
 FULL = [
     # name, batch, size, agents, r, steps, max_episode_steps, on_target modes
     ("configs1", 1024, 16, 8, 5, 24, 8, ("finish", "restart", "nothing")),

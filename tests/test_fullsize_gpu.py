@@ -96,7 +96,8 @@ def test_geometry_reports_the_store_flavour_as_executed():
         (9, torch.float32): 2, (9, torch.float16): 0, (9, torch.uint8): 0,   # window of 19 cells: beyond the 16-bit row masks
     }
     for (r, dt), policy in want.items():
-        env = VecPogema(GridConfig(size=24, num_agents=16, obs_radius=r, density=0.2, seed=1), batch=64, obs_dtype=dt)
+        env = VecPogema(GridConfig(size=24, num_agents=16, obs_radius=r, density=0.2, seed=1), batch=2048, obs_dtype=dt,
+                        reuse_buffers=False, placement_budget_gib=0)  # (>= 1024 envs: no helper waves; nothing is allocated)
         g = env.geometry()
         assert g["multi_wave"] == 0 and g["store_policy"] == policy, (r, dt, g)
         env.close()

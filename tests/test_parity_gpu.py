@@ -28,6 +28,7 @@ GEOMETRIES = [
     ("wide_window", 3, 20, 20, 10, 9, 0.1, 12, 8),       # single wave, generic path, W=19
     ("max_radius", 2, 12, 12, 5, 15, 0.1, 10, 8),        # PGX_MAX_OBS_RADIUS: W=31, window larger than the map
     ("a1024", 1, 52, 52, 1024, 2, 0.05, 5, 4),           # PGX_MAX_AGENTS: 16 waves (1024 threads) per env
+    ("big_map", 2, 640, 600, 20, 5, 0.2, 6, 4),          # near the LDS limit: two 650 x 610-cell bitmaps = 104 KB per workgroup
 ]
 
 

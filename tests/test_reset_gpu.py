@@ -139,7 +139,8 @@ def test_masked_regeneration_random_maps_epoch2():
 
 
 FULL = [("configs2", 8192, 64, 64, 5, 0.3), ("configs3_shard", 8192, 32, 16, 5, 0.3), ("configs4_part", 384, 256, 256, 7, 0.3),
-        ("configs1", 1024, 16, 8, 5, 0.3)]
+        ("configs1", 1024, 16, 8, 5, 0.3),
+        ("big_map", 3, 600, 20, 5, 0.25)]  # far beyond the LDS forest: union-find and component tables through L2, 360 000 cells
 
 
 @pytest.mark.parametrize("cfg", FULL, ids=[c[0] for c in FULL])

@@ -28,6 +28,8 @@ GEOMETRIES = [
     ("wide_window", 3, 20, 20, 10, 9, 0.1, 12, 8),       # single wave, generic path, W=19
     ("max_radius", 2, 12, 12, 5, 15, 0.1, 10, 8),        # PGX_MAX_OBS_RADIUS: W=31, window larger than the map
     ("a1024", 1, 52, 52, 1024, 2, 0.05, 5, 4),           # PGX_MAX_AGENTS: 16 waves (1024 threads) per env
+    ("tiny_map", 4, 2, 2, 2, 1, 0.0, 8, 4),              # the smallest map GridConfig admits: every cell a start or a target
+    ("one_row", 3, 1, 9, 3, 2, 0.0, 10, 5),              # a corridor one cell high: only left / right ever move, window taller than the map
     ("big_map", 2, 640, 600, 20, 5, 0.2, 6, 4),          # near the LDS limit: two 650 x 610-cell bitmaps = 104 KB per workgroup
 ]
 

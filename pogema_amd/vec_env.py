@@ -149,7 +149,9 @@ class VecPogema(PlacementMixin):
         cfg = _lib.PgxConfig(
             batch=self.batch, height=self.height, width=self.width, num_agents=self.num_agents,
             obs_radius=self.obs_radius, collision_system=_lib.COLLISION_SYSTEMS[gc.collision_system],
-            on_target=_lib.ON_TARGET[gc.on_target], max_episode_steps=int(gc.max_episode_steps),
+            # upstream's MultiTimeLimit truncates when `elapsed >= max_episode_steps`: with a limit <= 0 that is EVERY step,
+            # which is what a limit of 1 does; at the C-ABI a limit <= 0 means "no time limit" (include/pogema_amd.h)
+            on_target=_lib.ON_TARGET[gc.on_target], max_episode_steps=max(1, int(gc.max_episode_steps)),
             auto_reset=int(self.auto_reset), obs_dtype=_lib.OBS_DTYPES[self.obs_dtype], seed=int(gc.seed or 0),
             env_index_base=self.env_index_base, random_outside=0 if gc.empty_outside else 1,
             outside_density=float(gc.density), soft_vertex_rule=_lib.SOFT_VERTEX_RULES[self.semantics.soft_vertex],

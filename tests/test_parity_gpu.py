@@ -445,3 +445,20 @@ def test_lifelong_numpy_stream(geom, auto_reset):
     assert_rollouts_equal(ref, got, f"numpy lifelong/{name}/auto_reset={auto_reset}")
     base = oracle_rollout(obstacles, agents, targets, actions, **{**kw, "semantics": None})
     assert not np.array_equal(base["targets_xy"], ref["targets_xy"]), "the numpy stream differs from the build's stream"
+
+
+@pytest.mark.parametrize("limit", [1, 0, -3])
+@pytest.mark.parametrize("auto_reset", [False, True])
+def test_time_limit_edge_cases(limit, auto_reset):
+    """SURVEY A13, the literal `elapsed >= max_episode_steps`: a limit of 1 truncates every step, and so does a limit <= 0
+    (GridConfig admits it, upstream's wrapper does not special-case it) -- the Python mirror hands the engine a limit of 1
+    there; only at the C-ABI does a limit <= 0 mean 'no time limit'."""
+    B, H, Wd, A, r = 5, 9, 9, 6, 3
+    obstacles, agents, targets = generate_instances(B, H, Wd, A, 0.15, 4321)
+    actions = random_actions(6, B, A, 8)
+    for collision, on_target in (("priority", "finish"), ("soft", "restart")):
+        kw = dict(obs_radius=r, collision_system=collision, on_target=on_target, max_episode_steps=limit, auto_reset=auto_reset)
+        ref = oracle_rollout(obstacles, agents, targets, actions, **kw)
+        assert ref["truncated"].all(), "the literal time limit truncates every step for a limit <= 1"
+        got = engine_rollout(obstacles, agents, targets, actions, **kw)
+        assert_rollouts_equal(ref, got, f"limit={limit}/{collision}/{on_target}/auto_reset={auto_reset}")

@@ -2,6 +2,8 @@
 collision system / episode mode / auto-reset / action dtype / observation dtype, ragged batches) -- the HIP engine
 through the C-ABI against the plain-C oracle, bit-exact.  Complements the fixed geometry matrix of
 tests/test_parity_gpu.py with combinations nobody thought of."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -139,3 +141,11 @@ def test_random_device_resets(chunk):
                     assert np.array_equal(env._initial[0].cpu().numpy(), exp_o)
         env.close()
         done += 1
+
+
+def test_odd_configurations_engine_equals_python_oracle():
+    """The corner cases of tests/util.odd_cases (tiny / one-cell-wide maps, start on goal, shared goals, short time limits,
+    out-of-range actions, every semantics switch, `empty_outside` either way) through the engine, against the literal oracle."""
+    from util import assert_rollouts_equal, engine_rollout, odd_cases, oracle_rollout
+    for what, args, kw in odd_cases(20261002 + int(os.environ.get("PGX_FUZZ_SEED", "0")), 120):
+        assert_rollouts_equal(oracle_rollout(*args, **kw), engine_rollout(*args, **kw), what)

@@ -126,43 +126,12 @@ def test_random_outside_c_port_equals_python(r):
 
 
 def test_odd_configurations_python_oracle_equals_c_port():
-    """Differential fuzz over the corners random instance generators never visit: maps 1..6 cells wide (also a single row or
-    column), agents that START on their goal, several agents sharing one goal, goals on other agents' start cells, windows
-    larger than the map, time limits of 1-3 steps, out-of-range actions, every semantics switch, `empty_outside=False`,
-    lifelong streams keyed by odd (seed, env index) pairs -- the literal Python oracle against the plain-C port (which the
-    engine matches bit for bit, tests/test_parity_gpu.py).  (A time limit <= 0 is NOT in here: the C-ABI defines it as 'no
-    limit', the Python surface maps it to the literal behaviour -- tests/test_parity_gpu.py::test_time_limit_edge_cases.)"""
-    import numpy as np
-    from pogema_amd.semantics import Semantics
-    from util import assert_rollouts_equal, c_oracle_rollout, oracle_rollout
-    rng = np.random.default_rng(20261002)
-    done = 0
-    while done < 220:
-        H, W = int(rng.integers(1, 7)), int(rng.integers(1, 7))
-        A = int(rng.integers(1, max(2, min(H * W, 9))))
-        obst = (rng.random((H, W)) < float(rng.choice([0.0, 0.0, 0.15, 0.3]))).astype(np.uint8)
-        free = np.argwhere(obst == 0)
-        if len(free) < A:
-            continue
-        starts = free[rng.choice(len(free), A, replace=False)]
-        targets = free[rng.integers(0, len(free), A)]
-        if rng.random() < 0.3:
-            k = int(rng.integers(0, A))
-            targets[k] = starts[k]
-        if A >= 2 and rng.random() < 0.3:
-            targets[1] = targets[0]
-        T = int(rng.integers(1, 9))
-        actions = rng.integers(0, 5, size=(T, 1, A)).astype(np.int64)
-        if rng.random() < 0.2:
-            actions[rng.integers(0, T), 0, rng.integers(0, A)] = int(rng.choice([5, 7, 100]))
-        kw = dict(obs_radius=int(rng.integers(1, 4)), collision_system=str(rng.choice(["priority", "block_both", "soft"])),
-                  on_target=str(rng.choice(["finish", "restart", "nothing"])), max_episode_steps=int(rng.choice([1, 2, 3, 64])),
-                  auto_reset=bool(rng.random() < 0.5), seed=int(rng.integers(0, 1000)), env_index_base=int(rng.integers(0, 50)),
-                  empty_outside=bool(rng.random() < 0.7),
-                  semantics=Semantics(soft_vertex=str(rng.choice(["lowest_index", "all_stay"])),
-                                      soft_occupancy=str(rng.choice(["index_order", "exact"])),
-                                      coop_reward=str(rng.choice(["all_solved", "per_agent"]))))
-        args = (obst[None], starts[None].astype(np.int32), targets[None].astype(np.int32), actions)
-        assert_rollouts_equal(oracle_rollout(*args, **kw), c_oracle_rollout(*args, **kw),
-                              f"case {done}: {H}x{W}, {A} agents, {kw}, starts {starts.tolist()}, targets {targets.tolist()}")
-        done += 1
+    """Differential fuzz over the corners random instance generators never visit (tests/util.odd_cases): maps 1..6 cells wide
+    (also a single row or column), agents that START on their goal, several agents sharing one goal, goals on other agents'
+    start cells, windows larger than the map, time limits of 1-3 steps, out-of-range actions, every semantics switch,
+    `empty_outside=False`, lifelong streams keyed by odd (seed, env index) pairs -- the literal Python oracle against the
+    plain-C port; tests/test_fuzz_gpu.py runs the same cases through the engine.  (A time limit <= 0 is NOT in here: the C-ABI
+    defines it as 'no limit', the Python surface maps it to the literal behaviour -- test_time_limit_edge_cases.)"""
+    from util import assert_rollouts_equal, c_oracle_rollout, odd_cases, oracle_rollout
+    for what, args, kw in odd_cases(20261002, 220):
+        assert_rollouts_equal(oracle_rollout(*args, **kw), c_oracle_rollout(*args, **kw), what)

@@ -269,3 +269,40 @@ def check_spec_case(case, run):
         assert out["obs0"][0, 0].astype(int).tolist() == exp["obs0_agent0"]
     if "agents_plane" in exp:  # [T][A][W][W]: channel 1 (`Grid.get_positions`) of every agent's observation after each step
         assert out["obs"][:, 0, :, 1].astype(int).tolist() == exp["agents_plane"], f"agents plane: {case['why']}"
+
+
+def odd_cases(seed, n):
+    """(description, (obstacles, agents, targets, actions), rollout kwargs) for `n` single-environment corner cases: tiny and
+    one-cell-wide maps, agents starting on their goal, shared goals, goals on other agents' starts, short time limits,
+    out-of-range actions, random semantics switches, odd (seed, env index) pairs, `empty_outside` either way."""
+    from pogema_amd.semantics import Semantics
+    rng = np.random.default_rng(seed)
+    done = 0
+    while done < n:
+        H, W = int(rng.integers(1, 7)), int(rng.integers(1, 7))
+        A = int(rng.integers(1, max(2, min(H * W, 9))))
+        obst = (rng.random((H, W)) < float(rng.choice([0.0, 0.0, 0.15, 0.3]))).astype(np.uint8)
+        free = np.argwhere(obst == 0)
+        if len(free) < A:
+            continue
+        starts = free[rng.choice(len(free), A, replace=False)]
+        targets = free[rng.integers(0, len(free), A)]
+        if rng.random() < 0.3:
+            k = int(rng.integers(0, A))
+            targets[k] = starts[k]
+        if A >= 2 and rng.random() < 0.3:
+            targets[1] = targets[0]
+        T = int(rng.integers(1, 9))
+        actions = rng.integers(0, 5, size=(T, 1, A)).astype(np.int64)
+        if rng.random() < 0.2:
+            actions[rng.integers(0, T), 0, rng.integers(0, A)] = int(rng.choice([5, 7, 100]))
+        kw = dict(obs_radius=int(rng.integers(1, 4)), collision_system=str(rng.choice(["priority", "block_both", "soft"])),
+                  on_target=str(rng.choice(["finish", "restart", "nothing"])), max_episode_steps=int(rng.choice([1, 2, 3, 64])),
+                  auto_reset=bool(rng.random() < 0.5), seed=int(rng.integers(0, 1000)), env_index_base=int(rng.integers(0, 50)),
+                  empty_outside=bool(rng.random() < 0.7),
+                  semantics=Semantics(soft_vertex=str(rng.choice(["lowest_index", "all_stay"])),
+                                      soft_occupancy=str(rng.choice(["index_order", "exact"])),
+                                      coop_reward=str(rng.choice(["all_solved", "per_agent"]))))
+        what = f"odd case {done}: {H}x{W}, {A} agents, {kw}, starts {starts.tolist()}, targets {targets.tolist()}"
+        yield what, (obst[None], starts[None].astype(np.int32), targets[None].astype(np.int32), actions), kw
+        done += 1

@@ -233,3 +233,37 @@ def test_regenerate_failure_keeps_previous_instance():
     assert int(after["elapsed"].max()) == 0 and bool(after["is_active"].all())
     assert np.array_equal(env._initial[0].cpu().numpy(), np.broadcast_to(m, (5, 6, 6)))
     env.close()
+
+
+def test_odd_resets_equal_the_generator_oracle():
+    """The reset path in the corners: maps of 2..7 cells per side (rectangular through `map=` of free cells is not random --
+    so squares), 1 agent up to as many as fit, densities from 0 to 'almost full', odd env index bases, lifelong and not:
+    device reset == generator oracle, or BOTH say the instance cannot be placed."""
+    from pogema_amd import GridConfig, VecPogema, _lib
+    rng = np.random.default_rng(77)
+    placed = refused = 0
+    for case in range(60):
+        S = int(rng.integers(2, 8))
+        A = int(rng.integers(1, max(2, S * S // 2)))
+        density = float(rng.choice([0.0, 0.1, 0.3, 0.5, 0.7]))
+        seed, base, B = int(rng.integers(0, 10 ** 6)), int(rng.integers(0, 1000)), int(rng.integers(1, 6))
+        on_target = str(rng.choice(["finish", "restart", "nothing"]))
+        what = f"case {case}: {S}x{S}, {A} agents, density {density}, seed {seed}, base {base}, batch {B}, {on_target}"
+        try:
+            ro, ra, rt = G.generate_batch(seed, B, S, S, A, density, env_index_base=base)
+        except OverflowError:
+            ro = None
+        env = VecPogema(GridConfig(size=S, num_agents=A, obs_radius=int(rng.integers(1, 4)), density=density, seed=seed,
+                                   on_target=on_target), batch=B, env_index_base=base)
+        if ro is None:
+            with pytest.raises((_lib.PgxError, OverflowError)):
+                env.reset(seed=seed)
+            refused += 1
+        else:
+            env.reset(seed=seed)
+            maps, agents, targets = _device_state(env)
+            assert np.array_equal(maps, ro), f"{what}: obstacles"
+            assert np.array_equal(agents, ra) and np.array_equal(targets, rt), f"{what}: placement"
+            placed += 1
+        env.close()
+    assert placed >= 20 and refused >= 3, (placed, refused)

@@ -148,4 +148,6 @@ def test_odd_configurations_engine_equals_python_oracle():
     out-of-range actions, every semantics switch, `empty_outside` either way) through the engine, against the literal oracle."""
     from util import assert_rollouts_equal, engine_rollout, odd_cases, oracle_rollout
     for what, args, kw in odd_cases(20261002 + int(os.environ.get("PGX_FUZZ_SEED", "0")), 120):
-        assert_rollouts_equal(oracle_rollout(*args, **kw), engine_rollout(*args, **kw), what)
+        ref = oracle_rollout(*args, **kw)
+        assert_rollouts_equal(ref, engine_rollout(*args, **kw), what)
+        assert_rollouts_equal(ref, engine_rollout_launch(*args, **kw), what + " as one rollout launch")

@@ -203,6 +203,10 @@ def write_probes(pogema, GridConfig, pogema_v0, out_dir, failures):
         env = pogema_v0(GridConfig(seed=0, size=8, num_agents=2, obs_radius=2, density=0.1))
         env.reset(seed=0)
         g0 = grid_of(env)
+        # Q11: the declared spaces (metadata only: recalled as Box(-1.0, 1.0, (3, W, W)) for the default observation type,
+        # SURVEY says Box(0, 1, ...); the mirror declares 0..1)
+        probes["observation_space"] = repr(getattr(env, "observation_space", None))
+        probes["action_space"] = repr(getattr(env, "action_space", None))
         before = [list(map(int, p)) for p in agents_of(g0, 2)]
         try:
             env.step([7, 0])

@@ -716,6 +716,8 @@ int pgx_rollout(pgx_env* e, int32_t steps, const pgx_rollout_io* io, void* strea
     pgx::RolloutParams rp;
     rp.steps = steps;
     rp.obs_slots = io->obs ? io->obs_slots : 1;
+    rp.resident_bitmap = e->geo_roll.resident_bitmap ? 1 : 0;
+    rp.reserved0 = 0;
     rp.actions_stride = agents * action_bytes[io->action_dtype];
     rp.agents_stride = agents;
     rp.envs_stride = e->cfg.batch;

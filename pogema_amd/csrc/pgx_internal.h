@@ -117,6 +117,8 @@ struct StepParams {
 struct RolloutParams {
     int32_t steps;
     int32_t obs_slots;        // step t writes observation slot t % obs_slots
+    int32_t resident_bitmap;  // 1: the obstacle bitmap is staged once and keeps its own LDS region (StepGeometry::resident_bitmap)
+    int32_t reserved0;
     int64_t actions_stride;   // bytes between the action tensors of consecutive steps
     int64_t agents_stride;    // batch * num_agents: elements between per-agent outputs of consecutive steps
     int64_t envs_stride;      // batch: elements between per-env outputs of consecutive steps
@@ -136,6 +138,7 @@ struct StepGeometry {
     int stagger;      // > 0: odd wave slots sleep this many x 8128 cycles after issuing their loads
     int store_policy; // observation store flavour (pgx_kernels.hip: store_obs16)
     int state_stores; // when the per-step result stores are issued (pgx_kernels.hip: emit_state)
+    bool resident_bitmap;  // rollout launch shape only: obstacle bitmap staged once per launch, LDS = bitmap + max(rest, rows)
     size_t lds_bytes;
     // shares of the launch's workgroups per XCD (xcd_partition; equal until pgx_xcd_tune or PGX_XCD_WEIGHTS)
     int grid;             // workgroups to launch: 8 * the largest share

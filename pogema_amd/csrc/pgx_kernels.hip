@@ -19,6 +19,7 @@
 //   * integer indexing only -- no MFMA on purpose; the bound is HBM write bandwidth.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <array>
 #include <type_traits>
@@ -425,12 +426,25 @@ __device__ __forceinline__ void stream_rows16_edges(float* out, const uint16_t* 
 // ------------------------------------------------------------------------------------------------
 enum { MISC_FLAGS = 0, MISC_ARRIVED = 16, MISC_UNSOLVED = 17, MISC_OFFGOAL = 18, MISC_WORDS = 32 };
 
+// rollout_kernel (round 6): what a lane keeps in REGISTERS from one iteration of the on-device loop to the next -- the
+// agent's cell, target and is_active, its environment's time-limit counter and metric accumulators (leader lane), and
+// the caller's actions of eight steps at a time (4 bits each, 15 = out of range; `anext` is the block behind `ablk`,
+// fetched one block ahead).  HBM sees the agent / env state once before the first and once after the last step.
+struct Carry {
+    uint32_t pos = 0u, tgt = 1u;
+    uint32_t ablk = 0u, anext = 0u;
+    int elapsed = 0;
+    int4 macc = {0, 0, 0, 0};
+    bool active = false;
+};
+__device__ __forceinline__ uint32_t pack_action4(int a) { return (uint32_t)a <= 4u ? (uint32_t)a : 15u; }
+
 // P / R: the argument blocks, either plain (`const StepParams`, one step per launch) or read through a laundered
 // kernarg pointer (rollout_kernel).  ROLL: step `t` of a pgx_rollout launch -- the per-step I/O tensors are slices t of
 // the caller's [K, ...] buffers (observations: ring slot `slot`), addressed where they are used so that nothing but `t`
 // and `slot` lives across the loop.
 template <int G, bool MW, bool P16, bool ROLL, typename P, typename R>
-__device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int slot) {
+__device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int slot, Carry& c) {
     static_assert(!MW || G == 64, "multi-wave environments use full waves");
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
 
@@ -503,6 +517,63 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
     bool active = false;
     bool ghost_in = false;  // ACTIVE_GHOST of the stored byte (see `ghost` below)
     int act = 0, elapsed = 0;
+    int4 macc = make_int4(0, 0, 0, 0);
+    const bool env_leader = env_ok && agent == 0 && p.mode == MODE_STEP;
+    [[maybe_unused]] int araw[8];                 // ROLL: the actions of steps t+8 .. t+15 in flight (every eighth iteration)
+    [[maybe_unused]] bool fetch_block = false;
+    if constexpr (ROLL) {
+        // Register-resident loop: the state is loaded by the first iteration only and then carried in
+        // `c`.  gfx9 retires loads and stores through ONE in-order counter (vmcnt), so a load issued behind the observation
+        // stores of the previous iteration cannot be consumed before every one of those stores has been acknowledged
+        // (1.5-2 us for a lone wave: profiles/r6/rollout_timeline_before.txt) -- hence no per-iteration loads at all: the
+        // caller's actions arrive eight steps at a time, one block ahead, and are waited for once per block (below, behind
+        // the state phase); the random policy needs no load.
+        auto load_action = [&](size_t ai) -> int {
+            if (p.action_dtype == 0) return ((const int8_t*)p.actions)[ai];
+            if (p.action_dtype == 1) return ((const int32_t*)p.actions)[ai];
+            return (int)((const int64_t*)p.actions)[ai];
+        };
+        const bool given = p.actions != nullptr;
+        const int steps = rp.steps;
+        const size_t stride = (size_t)rp.agents_stride;
+        if (t == 0) {
+            if (valid) {
+                pos = p.pos[gi];
+                tgt = p.tgt[gi];
+                active = (p.active[gi] & ACTIVE_BIT) != 0;  // (ACTIVE_GHOST only matters to launches that LOOK at the state)
+                if (given) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) araw[k] = k < steps ? load_action(gi + (size_t)k * stride) : 0;
+                    uint32_t b = 0u;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) b |= pack_action4(araw[k]) << (4 * k);
+                    c.ablk = b;
+                }
+            }
+            if (env_ok) elapsed = p.elapsed[env];
+            if (env_leader) macc = p.macc[env];
+        } else {
+            pos = c.pos;
+            tgt = c.tgt;
+            active = c.active;
+            elapsed = c.elapsed;
+            macc = c.macc;
+        }
+        if (valid) {
+            if (!given) {  // the engine's own uniform random policy
+                act = policy_action((uint64_t)rp.policy_seed, (uint64_t)(p.env_index_base + env), (uint32_t)agent,
+                                    (uint64_t)(rp.policy_step0 + t));
+                if (rp.actions_out) rp.actions_out[gi + (size_t)t * stride] = (int8_t)act;
+            } else {
+                act = (int)((c.ablk >> (4 * (t & 7))) & 15u);
+                if ((t & 7) == 0 && t + 8 < steps) {
+                    fetch_block = true;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) araw[k] = t + 8 + k < steps ? load_action(gi + (size_t)(t + 8 + k) * stride) : 0;
+                }
+            }
+        }
+    } else {
     if (valid) {
         pos = p.pos[gi];
         tgt = p.tgt[gi];
@@ -510,27 +581,29 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
         active = (ab & ACTIVE_BIT) != 0;
         ghost_in = (ab & ACTIVE_GHOST) != 0;
         if (p.mode == MODE_STEP) {
-            const size_t ai = ROLL ? gi + (size_t)t * (size_t)rp.agents_stride : gi;
-            if (ROLL && p.actions == nullptr) {  // the engine's own uniform random policy
-                act = policy_action((uint64_t)rp.policy_seed, (uint64_t)(p.env_index_base + env), (uint32_t)agent,
-                                    (uint64_t)(rp.policy_step0 + t));
-                if (rp.actions_out) rp.actions_out[ai] = (int8_t)act;
-            } else if (p.action_dtype == 0) act = ((const int8_t*)p.actions)[ai];
-            else if (p.action_dtype == 1) act = ((const int32_t*)p.actions)[ai];
-            else act = (int)((const int64_t*)p.actions)[ai];
+            if (p.action_dtype == 0) act = ((const int8_t*)p.actions)[gi];
+            else if (p.action_dtype == 1) act = ((const int32_t*)p.actions)[gi];
+            else act = (int)((const int64_t*)p.actions)[gi];
         }
     }
     if (env_ok && p.mode == MODE_STEP) elapsed = p.elapsed[env];
-    int4 macc = make_int4(0, 0, 0, 0);
-    const bool env_leader = env_ok && agent == 0 && p.mode == MODE_STEP;
     if (env_leader) macc = p.macc[env];
+    }
 
     // ---- phase 1: stage obstacle bitmaps HBM -> LDS, clear the occupancy bitmaps ---------------
     {
         const uint32_t* g = p.obst + (size_t)env0 * bmw;
         const int n = nenv * bmw;
         const int stagger = (ROLL && t > 0) ? 0 : p.stagger;  // only the first step of a rollout starts in lockstep
-        if (!MW && stagger > 0 && n <= 16 * 64) {
+        // ROLL with a resident bitmap: the map does not change inside a launch, so the obstacle bitmap is staged by the
+        // first iteration only and stays in its own LDS region (the P16 row masks alias what lies BEHIND it); later
+        // iterations just clear the occupancy bitmap.
+        bool stage = true;
+        if constexpr (ROLL) stage = t == 0 || !rp.resident_bitmap;
+        if (!stage) {
+#pragma unroll 4
+            for (int i = tid; i < n; i += NT) s_occ[i] = 0u;
+        } else if (!MW && stagger > 0 && n <= 16 * 64) {
             // Two cohorts.  Every wave issues ALL its loads at t = 0, while the memory system is idle; then the waves in
             // odd hardware slots sleep for `stagger` x 8128 cycles.  The even slots run their state phase with half the
             // SIMD/LDS contention and start streaming early; the odd slots compute under that stream (their loads are
@@ -586,6 +659,8 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
     } so;
     const int when_stores = p.mode == MODE_STEP ? p.state_stores : 0;
     const bool late_stores = when_stores != 0;
+    [[maybe_unused]] bool last_step = true;
+    if constexpr (ROLL) last_step = t == rp.steps - 1;
     auto emit_state = [&](uint32_t pos_, uint32_t tgt_, bool active_, int elapsed_, int4 macc_, const StateOut& o) {
         const bool fin = p.on_target == ON_TARGET_FINISH, coop = p.on_target == ON_TARGET_NOTHING;
         if (valid) {
@@ -595,12 +670,14 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
             p.truncated[go] = o.trunc ? 1 : 0;
             if (p.act_out) p.act_out[go] = o.act ? 1 : 0;
             if (o.do_reset && p.np_state) p.np_state[gi] = p.np_state0[gi];  // upstream re-creates the generators in reset()
-            p.pos[gi] = pos_;
-            p.tgt[gi] = tgt_;
-            p.active[gi] = active_ ? (uint8_t)(ACTIVE_BIT | (ghost ? ACTIVE_GHOST : 0u)) : (uint8_t)0;
+            if (!ROLL || last_step) {  // (rollout: the agents' state leaves the registers after the last step only)
+                p.pos[gi] = pos_;
+                p.tgt[gi] = tgt_;
+                p.active[gi] = active_ ? (uint8_t)(ACTIVE_BIT | (ghost ? ACTIVE_GHOST : 0u)) : (uint8_t)0;
+            }
         }
         if (env_leader) {
-            p.elapsed[env] = o.do_reset ? 0 : elapsed_;
+            if (!ROLL || last_step) p.elapsed[env] = o.do_reset ? 0 : elapsed_;
             // ---- metric wrappers, fused: per-env accumulators, emitted when the episode finishes ----
             const int n_arrived = o.n_arrived;
             const int step = elapsed_ - 1;
@@ -630,7 +707,13 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
                 }
             }
             if (p.episode_done) p.episode_done[(size_t)env + (ROLL ? (size_t)t * (size_t)rp.envs_stride : 0)] = o.finished ? 1 : 0;
-            p.macc[env] = o.finished ? make_int4(0, 0, 0, 0) : macc_;
+            if constexpr (ROLL) {
+                if (o.finished) macc_ = make_int4(0, 0, 0, 0);
+                if (last_step) p.macc[env] = macc_;
+                c.macc = macc_;
+            } else {
+                p.macc[env] = o.finished ? make_int4(0, 0, 0, 0) : macc_;
+            }
         }
     };
     {
@@ -819,6 +902,18 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
             }
         }
     }
+    if constexpr (ROLL) {
+        c.pos = pos;
+        c.tgt = tgt;
+        c.active = active;
+        c.elapsed = so.do_reset ? 0 : elapsed;
+        if (fetch_block) {  // the one wait for loads in eight iterations: issued before the state phase, consumed behind it
+            uint32_t b = 0u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) b |= pack_action4(araw[k]) << (4 * k);
+            c.anext = b;
+        }
+    }
     if (dbg && tid == 0) p.dbg[(size_t)blk * 4 + (dbg2 ? 3 : 1)] = wall_clock64();
     if (!p.obs) {
         if (late_stores) emit_state(pos, tgt, active, elapsed, macc, so);
@@ -834,6 +929,8 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
         // known the 2 x W LDS reads of an item are issued back to back and waited for once -- before, every row paid its
         // own LDS round trip, a 16-cycle multiply and two scalar branches, which a lone wave pays in latency.
         const int W_rt = W, r_rt = r;
+        uint32_t* rows_base = smem;  // the packed rows go over the dead state -- in a rollout with a resident bitmap: behind it
+        if constexpr (ROLL) rows_base = rp.resident_bitmap ? s_occ : smem;
         auto p16_phases = [&](auto wt_tag) {
         constexpr int WT = decltype(wt_tag)::value;
         const int W = WT ? WT : W_rt;
@@ -909,7 +1006,7 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
             }
         }
         lds_sync<MW>();  // every lane has read the bitmaps / agent cells: the region may be overwritten
-        uint16_t* rows16 = reinterpret_cast<uint16_t*>(smem);
+        uint16_t* rows16 = reinterpret_cast<uint16_t*>(rows_base);
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             const int item = tid + t * NT;
@@ -992,7 +1089,7 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
         const bool span = MW && !(p.flags & 512u);
         const int part = (nvec + nw - 1) / nw;
         const int q0 = span ? wave * part + lane : tid, q1 = span ? min(nvec, (wave + 1) * part) : nvec;
-        stream_rows16_span<!ROLL>(reinterpret_cast<f32x4_t*>(out + head), reinterpret_cast<const uint32_t*>(rows16), head, W, magic,
+        stream_rows16_span<true>(reinterpret_cast<f32x4_t*>(out + head), reinterpret_cast<const uint32_t*>(rows16), head, W, magic,
                            (uint32_t)p.store_policy, q0, q1, span ? 64 : NT, (nag * 3 * W) >> 1);
         if (when_stores == 2) emit_state(pos, tgt, active, elapsed, macc, so);
         if (dbg && !dbg2 && tid == 0) {
@@ -1001,8 +1098,7 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
         }
         return;
         };
-        // (the rollout kernels keep the run-time form: they are at their register limit as it is)
-        if (ROLL || p.obs_u8 || p.obs_one) p16_phases(std::integral_constant<int, 0>{});
+        if (p.obs_u8 || p.obs_one) p16_phases(std::integral_constant<int, 0>{});
         else if (W_rt == 11) p16_phases(std::integral_constant<int, 11>{});
         else if (W_rt == 15) p16_phases(std::integral_constant<int, 15>{});
         else if (W_rt == 7) p16_phases(std::integral_constant<int, 7>{});
@@ -1116,24 +1212,37 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
 template <int G, bool MW, bool P16>
 __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const StepParams p) {
     const RolloutParams none{};
-    step_body<G, MW, P16, false>(p, none, 0, 0);
+    Carry unused;
+    step_body<G, MW, P16, false>(p, none, 0, 0, unused);
 }
 
 // K steps in ONE launch (pgx_rollout).  Environments never interact, so a workgroup can run its own environments
 // through all K steps without waiting for anybody else: step t of the launch reads actions[t] and writes the outputs
 // of slice t (observations: slot t % obs_slots).  Unlike K launches there is no launch boundary at which all waves
 // start their state phase together with HBM idle and finish together: after the first step the waves drift apart and
-// one wave's state phase runs under the other waves' observation streams.  Between two steps a wave waits for its own
-// stores (vmcnt counts loads and stores alike on gfx9, so the next step's loads could not be consumed earlier anyway):
-// that makes the state it wrote visible to its next iteration -- same CU, same vector L1; multi-wave workgroups add
-// the barrier.  Bit-identical with K pgx_step calls (tests/test_rollout_gpu.py).
+// one wave's state phase runs under the other waves' observation streams.
+// Round 6: a real on-device loop.  Until round 5 every iteration re-loaded pos / tgt / active / elapsed / macc and the
+// obstacle bitmap from HBM, stored them again and drained vmcnt(0) before the next one -- a K-step launch was no faster
+// than K launches where it matters (configs[1] 8.2 us per step against 7.9; per-iteration stamps of that kernel:
+// profiles/r6/rollout_timeline_before.txt -- 1.2 us loads + staging, 2 us run-time-W row masks, 2 us from the first
+// observation store to the last acknowledgement).  Now the agent / env state lives in registers (`Carry`), the obstacle
+// bitmap stays in LDS, the caller's actions are fetched eight steps at a time one block ahead, state goes back to HBM
+// after the last step, and NOTHING waits for a store: a wave's observation stores of step t are still in flight while it
+// resolves step t + 1 (the hardware's own limit of 64 outstanding vector-memory instructions per wave is the only
+// back-pressure).  Stores and later loads of one lane to the same address (tcount, np_state: lifelong) are kept in
+// order by the hardware.  Multi-wave workgroups keep one LDS barrier between iterations (the next iteration clears
+// what the slower waves still stream from) -- a barrier that no longer drains the vector-memory queue.
+// The launch runs at most PGX_ROLL_OCC (4) waves per SIMD: 128 VGPRs -- room for the carried state, the action block in
+// flight and the specialised (compile-time window side, software-pipelined) row / stream code of step_kernel, which the
+// 64-VGPR rollout kernels of rounds 3-5 had to do without; a loop that never waits does not need eight waves per SIMD
+// to keep HBM busy (in-process A/B of both builds: profiles/r6/).
+// Bit-identical with K pgx_step calls (tests/test_rollout_gpu.py).
 // The argument blocks are read through a kernarg pointer that is laundered once per iteration: otherwise LICM hoists
-// every argument load and every address computation of the (inlined) step out of the loop and the kernel needs > 100
-// VGPRs plus scratch where the single step needs < 50.
-template <int G, bool MW, bool P16>
+// every argument load and every address computation of the (inlined) step out of the loop.
 #ifndef PGX_ROLL_OCC
-#define PGX_ROLL_OCC 8
+#define PGX_ROLL_OCC 4
 #endif
+template <int G, bool MW, bool P16>
 __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : PGX_ROLL_OCC) void rollout_kernel(const StepParams p0, const RolloutParams rp0) {
     typedef const __attribute__((address_space(4))) char KC;
     typedef const __attribute__((address_space(4))) StepParams KP;
@@ -1143,15 +1252,16 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : PGX_ROLL_OCC) void rollout
     constexpr size_t rp_offset = (sizeof(StepParams) + alignof(RolloutParams) - 1) / alignof(RolloutParams) * alignof(RolloutParams);
     const int steps = rp0.steps, slots = rp0.obs_slots;
     int slot = 0;
+    Carry c;
     for (int t = 0; t < steps; ++t) {
         KC* ka = (KC*)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(ka));
         KP& p = *reinterpret_cast<KP*>(ka);
         KR& rp = *reinterpret_cast<KR*>(ka + rp_offset);
-        step_body<G, MW, P16, true>(p, rp, t, slot);
+        step_body<G, MW, P16, true>(p, rp, t, slot, c);
         slot = slot + 1 == slots ? 0 : slot + 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if constexpr (MW) __syncthreads();
+        if ((t & 7) == 7) c.ablk = c.anext;
+        if constexpr (MW) lds_sync<true>();
     }
 }
 
@@ -1361,6 +1471,26 @@ StepGeometry step_geometry(int batch, int A, int bmw, int W, bool allow_p16, int
         bytes = state_words * 4 > rows_bytes ? state_words * 4 : rows_bytes;
     } else {
         bytes = (state_words + nag * 3 * W + 1) * 4;
+    }
+    g.resident_bitmap = false;
+    if (for_rollout) {
+        // rollout_kernel stages the obstacle bitmap once per launch: it keeps its own LDS region and the P16 rows alias
+        // only what lies behind it.  Costs LDS when the rows are the larger part; if that no longer fits one CU the
+        // launch re-stages every iteration (layout of step_kernel).
+        const size_t bm_bytes = (size_t)g.epw * bmw * 4;
+        const size_t rest = state_words * 4 - bm_bytes;
+        size_t res;
+        if (g.p16) {
+            const size_t rows_bytes = (nag * 3 * W + 4) * 2;
+            res = bm_bytes + (rest > rows_bytes ? rest : rows_bytes);
+        } else {
+            res = bytes;
+        }
+        const char* off = getenv("PGX_ROLL_RESIDENT");  // diagnostic / tests: "0" forces the re-staging layout
+        if (res <= 160 * 1024 && !(off && off[0] == '0')) {
+            g.resident_bitmap = true;
+            bytes = res;
+        }
     }
     g.lds_bytes = (bytes + 15) & ~(size_t)15;
     return g;

@@ -15,14 +15,14 @@ for name in sys.argv[1:] or ["cfg1", "cfg3", "cfg2"]:
         env.step(acts[t])
     torch.cuda.synchronize()
     best = 1e9
-    for _ in range(3):
+    for _ in range(0 if os.environ.get("NO_STEP_LOOP") else 3):
         t0 = time.perf_counter()
         for t in range(K):
             env.step(acts[t])
         torch.cuda.synchronize()
         best = min(best, (time.perf_counter() - t0) / K * 1e6)
     line = f"{name}: step loop {best:8.2f} us/step"
-    for slots in (2, 1, 0):
+    for slots in [int(v) for v in os.environ.get("SLOTS", "2,1,0").split(",")]:
         env.rollout(acts[:4], obs_slots=slots)
         torch.cuda.synchronize()
         rb = 1e9

@@ -220,10 +220,24 @@ def _free_port() -> int:
 
 
 def visible_device_count() -> int:
-    """Number of HIP devices WITHOUT initialising the GPU in this process (the launcher must not: its children own
-    the devices).  torch.cuda.device_count() only enumerates on this image."""
-    import torch
-    return int(torch.cuda.device_count())
+    """Number of HIP devices WITHOUT touching the HIP runtime in this process (the launcher must not initialise the GPU:
+    its children own the devices).  Round 6: counted from sysfs -- the KFD topology nodes this process's
+    cgroup admits that have SIMDs (`box_fingerprint` reads the same files) -- narrowed by HIP_VISIBLE_DEVICES /
+    ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when set; only if sysfs shows nothing at all (no KFD: not a ROCm box)
+    does it fall back to torch.cuda.device_count(), which merely enumerates on this image."""
+    import glob
+    n = 0
+    for node in glob.glob("/sys/class/kfd/kfd/topology/nodes/[0-9]*"):
+        if _props(os.path.join(node, "properties")).get("simd_count"):
+            n += 1
+    if n == 0:
+        import torch
+        return int(torch.cuda.device_count())
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip()]))
+    return n
 
 
 def share_device() -> bool:
@@ -586,20 +600,32 @@ class EngineStep:
 
 class PipelinedStep:
     """Secondary figure: the same batch as TWO engines on two HIP streams, stepped alternately and never joined
-    (pogema_amd.PipelinedVecPogema -- double-buffered sampling).  One `step` here = one step of BOTH halves."""
+    (pogema_amd.PipelinedVecPogema -- double-buffered sampling).  One `step` here = one step of BOTH halves.
+    Round 6: with `parent`, the halves write their rows of two FULL-BATCH output sets borrowed from the
+    headline engine's recycler (buffers that engine has placed, timed and kept) instead of walking for buffers of their
+    own; without, both halves share ONE walk (PipelinedVecPogema._shared_walk) where round 5 ran two."""
 
-    def __init__(self, args, rank, device, batch, env_base, size, agents, r, parts=2):
+    def __init__(self, args, rank, device, batch, env_base, size, agents, r, parts=2, parent=None):
         import torch
         from pogema_amd import GridConfig, PipelinedVecPogema
         self.torch = torch
         gc = GridConfig(size=size, density=args.density, num_agents=agents, obs_radius=r, seed=0,
                         collision_system=args.collision, on_target=args.on_target,
                         max_episode_steps=args.max_episode_steps)
+        self.borrowed, parents = None, None
+        rec = getattr(parent, "_recycler", None) if parent is not None else None
+        if rec and rec.free_sets() >= 2 and tuple(parent.obs_shape)[0] == batch:
+            self.borrowed = [rec.take() for _ in range(2)]  # out of circulation for as long as this object lives
+            parents = [s[0] for s in self.borrowed]
+        self.buffers = "rows of two output sets of the headline engine" if parents else "own buffers, one walk shared by both halves"
+        self.placement_spread = bool((getattr(parent, "placement", None) or {}).get("spread", False)) if parents else None
+        kw = dict(obs_parents=parents) if parents else dict(reuse_buffers=True, placement_budget_gib=placement_budget(args))
         self.env = PipelinedVecPogema(gc, batch=batch, device=device, parts=parts, env_index_base=env_base, auto_reset=True,
-                                      reuse_buffers=True, placement_budget_gib=placement_budget(args),
-                                      obs_dtype=_torch_obs_dtype(args.obs_dtype))
+                                      obs_dtype=_torch_obs_dtype(args.obs_dtype), **kw)
         self.env.reset(seed=0)
         self.env.warm_buffers()
+        if self.placement_spread is None:
+            self.placement_spread = all(bool((e.placement or {}).get("spread", False)) for e in self.env.engines)
         tdt = {"int8": torch.int8, "int32": torch.int32, "int64": torch.int64}[args.action_dtype]
         gen = torch.Generator(device=device)
         gen.manual_seed(1 + rank)
@@ -628,36 +654,39 @@ class PipelinedStep:
 
     def close(self):
         self.env.close()
+        self.borrowed = None
 
 
 class RolloutStep:
-    """Secondary figure: K steps per launch (pgx_rollout), observation ring of two zone-spread slots -- the step
-    kernel's work with the launch boundaries between steps removed."""
+    """Secondary figure: K steps per launch (pgx_rollout) -- the step kernel's work as one on-device loop (agent / env
+    state in registers, no launch boundary, no store drain between steps).  Runs on the engine it is given (round 6: the
+    HEADLINE engine, whose rollout() borrows the ring from the output sets that engine has already placed and timed --
+    no walk of its own); `slots`: ring size, by default the smallest one of >= 1 GiB (a smaller ring is partly absorbed by
+    the 256 MiB Infinity Cache: profiles/r6/rollout_ring_sizes_and_helper_waves.txt)."""
 
-    def __init__(self, args, rank, device, batch, env_base, size, agents, r, k=64):
+    def __init__(self, args, rank, env, k=64, slots=None):
         import torch
-        from pogema_amd import GridConfig, VecPogema
-        self.torch, self.k = torch, k
-        gc = GridConfig(size=size, density=args.density, num_agents=agents, obs_radius=r, seed=0,
-                        collision_system=args.collision, on_target=args.on_target,
-                        max_episode_steps=args.max_episode_steps)
-        self.env = VecPogema(gc, batch=batch, device=device, env_index_base=env_base, auto_reset=True,
-                             placement_budget_gib=placement_budget(args),
-                             obs_dtype=_torch_obs_dtype(args.obs_dtype))
-        self.env.reset(seed=0)
+        self.torch, self.k, self.env = torch, k, env
+        batch, agents, r = env.batch, env.num_agents, env.obs_radius
         tdt = {"int8": torch.int8, "int32": torch.int32, "int64": torch.int64}[args.action_dtype]
-        gen = torch.Generator(device=device)
+        gen = torch.Generator(device=env.device)
         gen.manual_seed(1 + rank)
-        self.actions = torch.randint(0, 5, (k, batch, agents), generator=gen, device=device).to(tdt)
-        # ring of at least 1 GiB (and at least two slots): a smaller one would sit partly in the 256 MiB Infinity Cache
-        obs_bytes = batch * agents * 3 * (2 * r + 1) ** 2 * OBS_BYTES[args.obs_dtype]
-        self.slots = min(k, max(2, -(-(1 << 30) // obs_bytes)))
+        self.actions = torch.randint(0, 5, (k, batch, agents), generator=gen, device=env.device).to(tdt)
+        self.obs_bytes = batch * agents * 3 * (2 * r + 1) ** 2 * OBS_BYTES[args.obs_dtype]
+        self.slots = slots if slots is not None else min(k, max(2, -(-(1 << 30) // self.obs_bytes)))
+        self.ring = None
 
     def measure(self, steps, windows=3):
         torch = self.torch
         launches = max(1, steps // self.k)
-        self.env.rollout(self.actions, obs_slots=self.slots)
-        out = []
+        out = self.env.rollout(self.actions, obs_slots=self.slots)
+        rec = getattr(self.env, "_recycler", None)
+        ptrs = set(rec.obs_pointers()) if rec else set()
+        self.ring = ("output sets of this engine (recycler)" if out["obs"] is not None and out["obs"].data_ptr() in ptrs
+                     else "zone pool of its own" if self.slots in getattr(self.env, "_rollout_pools", {}) and
+                     self.env._rollout_pools[self.slots] is not None else "torch allocator (dense)")
+        del out
+        res = []
         for _ in range(windows):
             torch.cuda.synchronize()
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -666,11 +695,16 @@ class RolloutStep:
                 self.env.rollout(self.actions, obs_slots=self.slots)
             ev1.record()
             torch.cuda.synchronize()
-            out.append(ev0.elapsed_time(ev1) / (launches * self.k))
-        return statistics.median(out)
+            res.append(ev0.elapsed_time(ev1) / (launches * self.k))
+        return statistics.median(res)
 
-    def close(self):
-        self.env.close()
+    def fields(self, ms, alg_bytes):
+        ring_mib = self.slots * self.obs_bytes / float(1 << 20)
+        return {"steps_per_launch": self.k, "obs_slots": self.slots, "ring_mib": round(ring_mib, 1), "ring_memory": self.ring,
+                "ring_vs_infinity_cache": "HBM-sized (>= 1 GiB)" if ring_mib >= 1024 else
+                                          "within reach of the 256 MiB Infinity Cache: NOT an HBM figure",
+                "ms_per_step": ms, "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "placement_spread": bool((self.env.placement or {}).get("spread", False))}
 
 
 class StubStep:
@@ -689,6 +723,151 @@ class StubStep:
 
     def close(self):
         pass
+
+
+def headline_form(args, batch, per_gpu) -> bool:
+    """The default invocation (what the driver runs): the headline workload as the product runs it."""
+    return (args.workload == "cfg2" and args.obs_dtype == "float32" and batch == per_gpu and args.global_batch == 0
+            and args.buffers == 0 and args.graph == 0 and not args.no_obs and args.auto_reset == "restore")
+
+
+def measure_workload(args, name, rank, device):
+    """One more BASELINE config inside the headline process: a default-constructed engine of `name` (its own buffers: the
+    recycling allocator, a zone walk where the observation tensor is large enough to deserve one -- the line says what
+    it got), timed with HIP events over its own step() loop, then its rollout (ring borrowed from the engine's output
+    sets) and, for launches too short to hide the host, 32 steps per HIP graph."""
+    import copy
+    import torch
+    per_gpu, size, agents, r = WORKLOADS[name]
+    wargs = copy.copy(args)
+    wargs.workload, wargs.graph, wargs.buffers = name, 0, 0
+    bpas = algorithmic_bytes_per_agent_step(size, agents, r, OBS_BYTES[args.obs_dtype], {"int8": 1, "int32": 4, "int64": 8}[args.action_dtype])
+    alg_bytes = bpas * per_gpu * agents
+    obs_bytes = per_gpu * agents * 3 * (2 * r + 1) ** 2 * OBS_BYTES[args.obs_dtype]
+    n = 400 if obs_bytes < (64 << 20) else 200 if obs_bytes < (1 << 30) else 50
+    t_build = time.perf_counter()
+    st = EngineStep(wargs, rank, device, per_gpu, 0, size, agents, r)
+    build_s = time.perf_counter() - t_build
+    out = {"config": f"BASELINE.json configs[{name[-1]}]: {per_gpu} envs, {size}x{size} map, {agents} agents, obs_radius {r}",
+           "steps_timed": n, "algorithmic_bytes_per_launch": alg_bytes, "engine_build_s": round(build_s, 2)}
+    try:
+        st.run(max(10, n // 10))
+        ms = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            st.run(n)
+            ev1.record()
+            torch.cuda.synchronize()
+            ms.append(ev0.elapsed_time(ev1) / n)
+        step_ms = statistics.median(ms)
+        gbs = alg_bytes / (step_ms * 1e-3) / 1e9
+        box = st.box_store_stream_gbs()
+        pf = st.placement_fields()
+        geo = st.env.geometry()
+        out.update(ms_per_step=step_ms, value=per_gpu * agents / (step_ms * 1e-3), unit="agent-steps/s", achieved_gbs=gbs,
+                   frac=gbs / HBM_PEAK_GBS, box_store_stream_gbs=box, frac_of_box_store_stream=(gbs / box) if box else None,
+                   placement_spread=pf["spread"], placement_policy=pf["policy"], output_sets=pf["output_sets"],
+                   geometry={k: geo[k] for k in ("lanes_per_env", "waves", "envs_per_wave", "multi_wave", "p16", "grid", "lds_bytes") if k in geo})
+        rs = RolloutStep(wargs, rank, st.env, slots=2)
+        out["rollout"] = rs.fields(rs.measure(max(64, n)), alg_bytes)
+        out["rollout_ms_per_step"] = out["rollout"]["ms_per_step"]
+        out["rollout"]["geometry"] = {k: v for k, v in st.env.geometry(for_rollout=True).items()
+                                      if k in ("lanes_per_env", "waves", "envs_per_wave", "grid", "lds_bytes")}
+        if obs_bytes * 2 < (1 << 30):  # ... and into a ring that the Infinity Cache cannot hold: dense torch memory (no walk)
+            probe, st.env.placement_probe = st.env.placement_probe, False
+            try:
+                rh = RolloutStep(wargs, rank, st.env)
+                out["rollout_hbm_ring"] = rh.fields(rh.measure(max(64, n)), alg_bytes)
+            finally:
+                st.env.placement_probe = probe
+            del rh
+        del rs
+    finally:
+        st.close()
+        del st
+        torch.cuda.empty_cache()
+    if obs_bytes < (256 << 20):
+        gargs = copy.copy(wargs)
+        gargs.graph = 32
+        gs = EngineStep(gargs, rank, device, per_gpu, 0, size, agents, r)
+        try:
+            reps = max(1, n // 32)
+            gs.run(64)
+            g_ms = []
+            for _ in range(3):
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                ev0.record()
+                gs.run(32 * reps)
+                ev1.record()
+                torch.cuda.synchronize()
+                g_ms.append(ev0.elapsed_time(ev1) / (32 * reps))
+            out["graph_ms_per_step"] = statistics.median(g_ms)
+        finally:
+            gs.close()
+            del gs
+    return out
+
+
+WORKLOAD_KEYS = ("config", "ms_per_step", "value", "frac", "frac_of_box_store_stream", "rollout_ms_per_step", "rollout",
+                 "geometry", "placement_spread")  # + graph_ms_per_step for the short launches (cfg1, cfg3)
+
+
+def stub_workload(name):
+    """TEST ONLY (`--stub`): the record of measure_workload with host sleeps instead of engines, so that the CPU suite can
+    pin the key set of secondary.workloads (tests/test_bench_launch.py)."""
+    per_gpu, size, agents, r = WORKLOADS[name]
+    st = StubStep(0)
+    t0 = time.perf_counter()
+    st.run(4)
+    ms = (time.perf_counter() - t0) / 4 * 1e3
+    alg = algorithmic_bytes_per_agent_step(size, agents, r) * per_gpu * agents
+    rec = {"config": f"STUB configs[{name[-1]}]", "ms_per_step": ms, "value": per_gpu * agents / (ms * 1e-3), "unit": "agent-steps/s",
+           "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "frac_of_box_store_stream": None, "placement_spread": False,
+           "geometry": {}, "rollout": {"ms_per_step": ms, "obs_slots": 2}, "rollout_ms_per_step": ms}
+    if per_gpu * agents * 3 * (2 * r + 1) ** 2 * 4 < (256 << 20):
+        rec["graph_ms_per_step"] = ms
+    return rec
+
+
+def configs0_cpu_baseline(seconds=2.0):
+    """BASELINE.json configs[0] -- GridConfig(size=8, num_agents=2, obs_radius=3, density=0.3), ONE env, the reference's own
+    CPU-runnable case -- on the pure-Python literal oracle (the closest thing to the reference's step() that exists here)
+    and on the plain-C port, one core each."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import generate_instances
+    from oracle.pogema_oracle import PogemaOracle
+    from oracle.c_oracle import COracle
+    size, agents, r = 8, 2, 3
+    obstacles, agents_xy, targets_xy = generate_instances(1, size, size, agents, 0.3, 0)
+    pool = np.random.default_rng(1).integers(0, 5, size=(64, 1, agents)).astype(np.int64)
+    env = PogemaOracle(obstacles[0], agents_xy[0], targets_xy[0], obs_radius=r, collision_system="priority", on_target="finish",
+                       max_episode_steps=64, auto_reset=True)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        env.step(pool[n % 64][0])
+        n += 1
+    dt = time.perf_counter() - t0
+    res = {"value": agents * n / dt, "unit": "agent-steps/s", "cores": 1, "kind": "port", "env_steps_per_s": n / dt,
+           "sample": f"1 env x {agents} agents x {n} steps, GridConfig(size=8, num_agents=2, obs_radius=3, density=0.3), "
+                     f"pure-Python literal oracle, {dt:.1f} s wall"}
+    c = COracle(1, size, size, agents, r, "priority", "finish", 64, True)
+    c.reset(obstacles, agents_xy, targets_xy)
+    W = 2 * r + 1
+    out = (np.empty((1, agents, 3, W, W), np.float32), np.empty((1, agents), np.float32), np.empty((1, agents), np.uint8),
+           np.empty((1, agents), np.uint8), np.empty((1, agents), np.uint8))
+    m, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < 0.5:
+        c.step(pool[m % 64], nthreads=1, out=out)
+        m += 1
+    cdt = time.perf_counter() - t0
+    c.close()
+    res["c_port"] = {"value": agents * m / cdt, "unit": "agent-steps/s", "cores": 1, "kind": "port", "env_steps_per_s": m / cdt,
+                     "sample": f"1 env x {agents} agents x {m} steps, plain-C oracle port through ctypes (call overhead included)"}
+    return res
 
 
 def make_parser():
@@ -885,18 +1064,25 @@ def main(argv=None):
                 extra_errors["held_pair"] = repr(exc)
         if batch % 2 == 0:
             try:  # a secondary figure must never cost the headline line
+                # (a) the halves write their rows of two full-batch output sets of the headline engine: no walk, no verdict
+                # of their own -- but each half's rows lie in ONE zone of such a buffer; (b) buffers of their own, placed
+                # by ONE walk shared by both halves (PipelinedVecPogema._shared_walk)
+                ps = PipelinedStep(args, rank, device, batch, env_base, size, agents, r, parent=step.env)
+                rows = {"ms_per_step": ps.measure(n), "buffers": ps.buffers, "placement_spread": ps.placement_spread}
+                ps.close()
+                del ps
+                torch.cuda.empty_cache()
                 ps = PipelinedStep(args, rank, device, batch, env_base, size, agents, r)
-                extras["pipelined"] = {"engines": 2, "ms_per_step": ps.measure(n)}
+                extras["pipelined"] = {"engines": 2, "ms_per_step": ps.measure(n), "buffers": ps.buffers,
+                                       "placement_spread": ps.placement_spread, "rows_of_headline_sets": rows}
                 ps.close()
                 del ps
             except Exception as exc:  # noqa: BLE001
                 extra_errors["pipelined"] = repr(exc)
             torch.cuda.empty_cache()
         try:
-            rs = RolloutStep(args, rank, device, batch, env_base, size, agents, r)
-            extras["rollout"] = {"steps_per_launch": rs.k, "obs_slots": rs.slots, "ms_per_step": rs.measure(n),
-                                 "placement_spread": bool((rs.env.placement or {}).get("spread", False))}
-            rs.close()
+            rs = RolloutStep(args, rank, step.env)
+            extras["rollout"] = rs.fields(rs.measure(n), bpas * batch * agents)
             del rs
         except Exception as exc:  # noqa: BLE001
             extra_errors["rollout"] = repr(exc)
@@ -931,8 +1117,23 @@ def main(argv=None):
             extras["host_gather"] = step.measure_host_gather(min(n, 400), total_envs)
         except Exception as exc:  # noqa: BLE001
             extra_errors["host_gather"] = repr(exc)
+        # every other BASELINE GPU config in the driver's one line: default-constructed engines of
+        # configs[1], the configs[3] shard and configs[4] in this same process, each with its step() loop, its rollout and
+        # (short launches) its HIP-graph figure; a failure lands in `errors`, never costs the line
+        if headline_form(args, batch, per_gpu):
+            extras["workloads"] = {}
+            for name in ("cfg1", "cfg3", "cfg4"):
+                if name == args.workload:
+                    continue
+                try:
+                    extras["workloads"][name] = measure_workload(args, name, rank, device)
+                except Exception as exc:  # noqa: BLE001
+                    extra_errors["workloads." + name] = repr(exc)
+                torch.cuda.empty_cache()
         if extra_errors:
             extras["errors"] = extra_errors
+    elif args.stub and not args.no_extras and world == 1 and headline_form(args, batch, per_gpu):
+        extras["workloads"] = {name: stub_workload(name) for name in ("cfg1", "cfg3", "cfg4")}
     elif not args.stub and not args.no_extras and world > 1 and args.graph <= 0 and not args.no_obs:
         # N > 1: the gather is the one cross-rank piece of the product path -- every rank takes part (shared segment,
         # gloo barrier per step); a failure on any rank must not cost the line, so the verdict is agreed first
@@ -1033,10 +1234,10 @@ def main(argv=None):
         if "rollout" in extras:
             e = extras["rollout"]
             e.update(value=batch * agents / (e["ms_per_step"] * 1e-3), unit="agent-steps/s",
-                     frac=alg_bytes / (e["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     what="pgx_rollout: 64 steps per launch with the actions given up front, observations into a ring of "
-                          "obs_slots tensors (>= 1 GiB in total); bit-identical with 64 pgx_step calls; HIP events around the "
-                          "launches")
+                     what="pgx_rollout on the headline engine: 64 steps per launch with the actions given up front -- one "
+                          "on-device loop, agent / env state in registers, nothing waits for a store -- observations into a "
+                          "ring of obs_slots tensors (>= 1 GiB in total) borrowed from that engine's own output sets; "
+                          "bit-identical with 64 pgx_step calls; HIP events around the launches")
         if "graph" in extras:
             e = extras["graph"]
             e.update(value=batch * agents / (e["ms_per_step"] * 1e-3), unit="agent-steps/s",
@@ -1067,9 +1268,16 @@ def main(argv=None):
             try:  # the baseline leg must never cost the measured line
                 line["cpu_baseline"] = cpu_baseline(size, agents, r, args.collision, args.density, args.max_episode_steps,
                                                     args.cpu_seconds)
+                try:
+                    line["cpu_baseline"]["configs0_python_literal"] = configs0_cpu_baseline()
+                except Exception as exc:  # noqa: BLE001
+                    line["cpu_baseline"]["configs0_python_literal"] = {"value": None, "sample": f"FAILED: {exc!r}"}
             except Exception as exc:  # noqa: BLE001
                 line["cpu_baseline"] = {"value": None, "unit": "agent-steps/s", "cores": 0, "kind": "port",
                                         "sample": f"FAILED: {exc!r}"}
+        elif world == 1 and not args.no_cpu_baseline and args.stub:  # (tests: the configs[0] leg runs on the CPU for real)
+            line["cpu_baseline"] = {"value": None, "unit": "agent-steps/s", "cores": 0, "kind": "port", "sample": "stub",
+                                    "configs0_python_literal": configs0_cpu_baseline(0.3)}
         print(json.dumps(line), flush=True)
     step.close()
     if use_dist:

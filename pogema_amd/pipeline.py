@@ -16,6 +16,12 @@ separate object with per-part calls and not something step() of a single engine 
 
 Part i holds the global envs [i * batch / S, (i + 1) * batch / S): the instances, the lifelong target streams and every
 result are those of ONE engine over the whole batch (tests/test_pipeline_gpu.py).
+
+`obs_parents` (round 6): FULL-BATCH observation tensors the caller already owns -- typically the output sets of a
+VecPogema over the whole batch, placed and timed once.  The parts then write their rows of those tensors in turn
+(step k of every part goes to parent k % len(parents)) instead of each part placing buffers of its own with a walk of its
+own: the batch's observations land in one contiguous [batch, agents, 3, W, W] tensor, and the placement verdict of the
+parent engine is the pipeline's (bench.py's `pipelined` figure no longer rolls its own dice).
 """
 from __future__ import annotations
 
@@ -29,9 +35,11 @@ from .vec_env import VecPogema
 
 class PipelinedVecPogema:
     def __init__(self, grid_config: Optional[GridConfig] = None, batch: int = 2, device="cuda:0", parts: int = 2,
-                 env_index_base: int = 0, **engine_kwargs):
+                 env_index_base: int = 0, obs_parents=None, **engine_kwargs):
         if parts < 1 or batch % parts != 0:
             raise ValueError(f"batch ({batch}) must be a positive multiple of parts ({parts})")
+        if obs_parents is not None:
+            engine_kwargs = dict(engine_kwargs, reuse_buffers=False)  # every step gets out=(rows of a parent, ...)
         self.parts = int(parts)
         self.batch = int(batch)
         self.part_batch = self.batch // self.parts
@@ -45,6 +53,24 @@ class PipelinedVecPogema:
         self.grid_config = self.engines[0].grid_config
         self.num_agents = self.engines[0].num_agents
         self.obs_shape = (self.batch,) + tuple(self.engines[0].obs_shape[1:])
+        self._parents, self._sets, self._turn = None, None, [0] * self.parts
+        if obs_parents is not None:
+            obs_parents = list(obs_parents)
+            e0 = self.engines[0]
+            for t in obs_parents:
+                if (tuple(t.shape) != self.obs_shape or t.dtype != e0.obs_dtype or not t.is_contiguous()
+                        or t.device != e0.device):
+                    raise ValueError(f"obs_parents must be contiguous {e0.obs_dtype} tensors of shape {self.obs_shape} on {e0.device}")
+            if not obs_parents:
+                raise ValueError("obs_parents is empty")
+            self._parents = obs_parents
+            B, A, dev = self.batch, self.num_agents, self.device
+            # per parent: the small per-step outputs of the whole batch, written by the parts row-wise as well
+            self._sets = [(t, torch.empty((B, A), dtype=torch.float32, device=dev), torch.empty((B, A), dtype=torch.bool, device=dev),
+                           torch.empty((B, A), dtype=torch.bool, device=dev), torch.empty((B, A), dtype=torch.bool, device=dev))
+                          for t in obs_parents]
+            # (row views made once: five slices per step and part would be ~10 us of host time in the loop)
+            self._rows = [[tuple(t[self.part_slice(i)] for t in st) for i in range(self.parts)] for st in self._sets]
 
     def stream(self, i: int):
         """Context manager: torch work issued inside runs on part i's stream (policy inference for that half)."""
@@ -62,17 +88,56 @@ class PipelinedVecPogema:
         return out
 
     def warm_buffers(self):
-        """`VecPogema.warm_buffers` of every part (zone walk and candidate timing outside the sampling loop)."""
+        """`VecPogema.warm_buffers` of every part (zone walk and candidate timing outside the sampling loop).  With
+        `obs_parents` there is nothing to place: only the parts' XCD shares are tuned on their rows of the parents."""
         out = []
         for i, e in enumerate(self.engines):
             with self.stream(i):
-                out.append(e.warm_buffers())
+                if self._parents is not None:
+                    sl = self.part_slice(i)
+                    info = {}
+                    if e.batch >= 2048 and e._has_state():
+                        info = e.tune_xcd_shares(self._parents[0][sl], self._parents[-1][sl] if len(self._parents) > 1 else None)
+                    out.append(dict(info, method="rows of the caller's full-batch tensors (obs_parents)"))
+                elif self._shared_walk(i):
+                    out.append(e.placement or {})
+                else:
+                    out.append(e.warm_buffers())
         return out
+
+    def _shared_walk(self, i: int) -> bool:
+        """reuse_buffers=True: ONE placement for all parts (round 6) -- part 0 picks 2 x parts observation buffers of the
+        part shape in a single walk (candidates timed, the best kept, as for a lone engine) and every part adopts its
+        pair, instead of `parts` engines each holding half of the free memory for a walk of their own and each rolling
+        their own verdict.  True when part i got (or already had) its buffers this way."""
+        e0 = self.engines[0]
+        if self.parts < 2 or not e0.reuse_buffers or e0.single_buffer or not e0._has_state():
+            return False
+        if any(e._bufs is not None for e in self.engines) and getattr(self, "_shared_bufs", None) is None:
+            return False  # somebody has placed buffers already (a step before warm_buffers)
+        if getattr(self, "_shared_bufs", None) is None:
+            with self.stream(0):
+                self._shared_bufs = e0._pick_obs_buffers(2 * self.parts)
+                self._shared_placement = dict(e0.placement or {}, shared_by_parts=self.parts)
+        if self.engines[i]._bufs is None:
+            self.engines[i].adopt_obs_buffers(self._shared_bufs[2 * i:2 * i + 2], self._shared_placement)
+            if self.engines[i]._zone_ptrs is not None:
+                self.engines[i]._zone_ptrs = set(e0._zone_ptrs)
+        return True
+
+    def parent_outputs(self, k: int):
+        """(obs, rewards, terminated, truncated, is_active) of parent k over the WHOLE batch (obs_parents only); rows of
+        part i are valid on stream i / after `wait_part(i)`."""
+        return self._sets[k]
 
     def step_part(self, i: int, actions, **kw):
         """`VecPogema.step` of part i, enqueued on part i's stream; `actions`: [batch / parts, agents].  If the actions
         were produced on another stream, make part i's stream wait for them first (`wait_for`)."""
         with self.stream(i):
+            if self._sets is not None and "out" not in kw:
+                k = self._turn[i]
+                self._turn[i] = (k + 1) % len(self._sets)
+                kw = dict(kw, out=self._rows[k][i])
             return self.engines[i].step(actions, **kw)
 
     def step(self, actions, **kw):

@@ -96,7 +96,15 @@ class PlacementMixin:
             n = 1 if self.single_buffer else 2
         if not self.placement_probe or obs_bytes < self.PLACEMENT_MIN_BYTES:
             return self._plain_obs_buffers(n)
-        from .buffers import walk_lock
+        from .buffers import ParkedBuffers, walk_lock
+        parked = ParkedBuffers.claim(self._shelf_key(), n)
+        if parked is not None:  # buffers a closed environment of this shape left behind: no walk (as _build_recycler)
+            bufs, info = parked
+            self._zone_ptrs = {t.data_ptr() for t in bufs}
+            self.placement = dict(info, method="pgx_buffers (two HBM zones per buffer; taken over from a closed environment)")
+            if self.batch >= 2048 and self._has_state():
+                self.placement.update(self.tune_xcd_shares(bufs[0], bufs[-1] if n > 1 else None))
+            return bufs
         budget, why, explicit = self._walk_policy()
         if budget <= 0.0:
             return self._plain_obs_buffers(n, policy=why)
@@ -295,6 +303,42 @@ class PlacementMixin:
             return float(us.value)
         _lib.check(self._lib.pgx_time_observe(self._handle, obs.data_ptr(), 3, C.byref(us), self._stream()))
         return float(us.value)
+
+    def _ring_from_recycler(self, slots: int, obs_bytes: int):
+        """rollout()'s observation ring out of the output sets of reuse_buffers='recycle' (VERDICT r5 next #4): `slots` idle
+        sets are taken like any other hand-out and stay out for as long as the returned ring tensor (or a view of it) is
+        alive -- step() then serves from the remaining sets or fresh tensors, and nothing is overwritten behind the
+        caller's back.  The buffers need not be neighbours: the kernel addresses slot k at base + k * stride, so any two
+        buffers form a ring (stride = their distance), more only when they happen to lie at equal distances.
+        -> (ring [slots, *obs_shape] strided view, stride in bytes) or None (not in recycle mode, more slots than sets, sets
+        in use, unequal distances): the caller falls back to a ring of its own (`_build_rollout_ring`)."""
+        if not self.recycle or self._recycler is False:
+            return None
+        if self._recycler is None:
+            if not self._has_state() or torch.cuda.is_current_stream_capturing():
+                return None
+            self._recycler = self._build_recycler()
+        rec = self._recycler
+        if not rec or slots > len(rec) or rec.free_sets() < slots:
+            return None
+        taken = [rec.take() for _ in range(slots)]
+        if any(s is None for s in taken):
+            return None
+        taken.sort(key=lambda s: s[0].data_ptr())
+        ptrs = [s[0].data_ptr() for s in taken]
+        stride = ptrs[1] - ptrs[0] if slots > 1 else obs_bytes
+        if stride < obs_bytes or stride % 16 or any(ptrs[i + 1] - ptrs[i] != stride for i in range(slots - 1)):
+            return None
+        from .buffers import _Cai, _TYPESTR
+        item = _lib.obs_elem_bytes(self.obs_dtype)
+        dense = [item]
+        for n in reversed(tuple(self.obs_shape)[1:]):
+            dense.insert(0, dense[0] * n)
+        ring = torch.as_tensor(_Cai(ptrs[0], (slots,) + tuple(self.obs_shape), _TYPESTR[self.obs_dtype], taken,
+                                    strides=(stride,) + tuple(dense)), device=self.device)
+        if ring.data_ptr() != ptrs[0] or ring.stride(0) * item != stride:
+            return None
+        return (ring if ring.dtype == self.obs_dtype else ring.view(self.obs_dtype)), stride
 
     def _build_rollout_ring(self, slots: int, obs_bytes: int):
         """(pool, ring view) of `slots` zone-spread observation slots for rollout(), or None (no walk under the policy of

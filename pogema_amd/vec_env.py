@@ -467,6 +467,25 @@ class VecPogema(PlacementMixin):
 
 
 
+    def adopt_obs_buffers(self, tensors, placement: Optional[dict] = None):
+        """reuse_buffers=True / 'single': use these observation tensors (placed by somebody else -- another engine's walk, the
+        caller's own allocator) as the alternating output sets instead of picking buffers with a walk of this engine's own.
+        `placement`: what is known about where they lie (becomes `self.placement`)."""
+        if not self.reuse_buffers:
+            raise ValueError("adopt_obs_buffers needs reuse_buffers=True or 'single'")
+        tensors = list(tensors)
+        if len(tensors) != (1 if self.single_buffer else 2):
+            raise ValueError(f"need {1 if self.single_buffer else 2} observation tensor(s), got {len(tensors)}")
+        for t in tensors:
+            if t.dtype != self.obs_dtype or tuple(t.shape) != self.obs_shape or not t.is_contiguous() or t.device != self.device:
+                raise ValueError(f"observation buffers must be contiguous {self.obs_dtype} tensors of shape {self.obs_shape} on {self.device}")
+        self._bufs = [(obs,) + self._alloc_outputs(False)[1:] for obs in tensors]
+        self._buf_i = 0
+        self.placement = dict(placement or {}, adopted=True)
+        if self.placement_probe and self.batch >= 2048 and self._has_state():
+            self.placement.update(self.tune_xcd_shares(tensors[0], tensors[-1] if len(tensors) > 1 else None))
+        return self.placement
+
     def _has_state(self):
         return self._initial is not None
 
@@ -610,7 +629,13 @@ class VecPogema(PlacementMixin):
         obs, slot_stride = None, 0
         if slots:
             obs_bytes = int(np.prod(self.obs_shape)) * _lib.obs_elem_bytes(self.obs_dtype)
-            if self.placement_probe and slots <= 8 and obs_bytes >= self.PLACEMENT_MIN_BYTES:
+            if self.placement_probe and obs_bytes >= self.PLACEMENT_MIN_BYTES:
+                # first choice: output sets the engine has already placed, timed and kept (reuse_buffers='recycle') --
+                # borrowed for as long as the caller holds the returned ring, no second walk, no second verdict
+                borrowed = self._ring_from_recycler(slots, obs_bytes)
+                if borrowed is not None:
+                    obs, slot_stride = borrowed
+            if obs is None and self.placement_probe and slots <= 8 and obs_bytes >= self.PLACEMENT_MIN_BYTES:
                 if slots not in self._rollout_pools:  # decided once per ring size (None = no ring: dense torch memory)
                     self._rollout_pools[slots] = self._build_rollout_ring(slots, obs_bytes)
                 entry = self._rollout_pools[slots]

@@ -108,3 +108,44 @@ def test_rccl_fallback_is_a_collective_decision(fake):
     assert label.startswith("gloo (RCCL unusable on ") and "of 2 ranks" in label
     assert "RCCL is not usable on rank" in p.stderr
     assert line["n_gpus"] == 2 and len(line["roofline"]["per_rank"]) == 2
+
+
+def test_default_form_carries_every_baseline_config():
+    """the driver's one line (N = 1, default workload) carries configs[1], the configs[3] shard and
+    configs[4] under secondary.workloads with a fixed key set, and the configs[0] shape (size 8, 2 agents, r 3, ONE env) on
+    the CPU under cpu_baseline.configs0_python_literal.  Stub mode pins the keys; the values are measured on the GPU box."""
+    from bench import WORKLOAD_KEYS
+    line = _stub_line(_run(["--gpus", "1", "--stub", "--steps", "5", "--warmup", "1", "--windows", "1"]))
+    wl = line["secondary"]["workloads"]
+    assert sorted(wl) == ["cfg1", "cfg3", "cfg4"]
+    for name, rec in wl.items():
+        for key in WORKLOAD_KEYS:
+            assert key in rec, (name, key)
+        assert ("graph_ms_per_step" in rec) == (name in ("cfg1", "cfg3")), name
+    c0 = line["cpu_baseline"]["configs0_python_literal"]
+    assert c0["value"] > 0 and c0["cores"] == 1 and "size=8, num_agents=2, obs_radius=3" in c0["sample"]
+    assert c0["c_port"]["value"] > 0
+    # a non-default workload does not drag the others along
+    other = _stub_line(_run(["--gpus", "1", "--stub", "--steps", "5", "--warmup", "1", "--windows", "1", "--workload", "cfg3"]))
+    assert "workloads" not in (other.get("secondary") or {})
+
+
+def test_launcher_counts_devices_from_sysfs_not_hip(monkeypatch, tmp_path):
+    """the self-launcher must provably not initialise HIP before it spawns its ranks: devices are counted
+    from the KFD topology in sysfs (narrowed by *_VISIBLE_DEVICES); torch is only asked where there is no KFD at all."""
+    import glob as _glob
+    import bench
+    nodes = tmp_path / "nodes"
+    for i, simd in enumerate((0, 1024, 1024, 1024)):  # node 0 = the CPU
+        (nodes / str(i)).mkdir(parents=True)
+        (nodes / str(i) / "properties").write_text(f"cpu_cores_count {64 if simd == 0 else 0}\nsimd_count {simd}\n")
+    real = _glob.glob
+    monkeypatch.setattr(_glob, "glob", lambda pat, *a, **k: sorted(str(p) for p in nodes.iterdir())
+                        if pat.startswith("/sys/class/kfd/kfd/topology/nodes/") else real(pat, *a, **k))
+    import torch
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: (_ for _ in ()).throw(AssertionError("HIP must not be asked")))
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert bench.visible_device_count() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.visible_device_count() == 2

@@ -75,3 +75,31 @@ def test_argument_errors():
         pipe.step(torch.zeros((3, 2), dtype=torch.int8, device=DEV))
     with pytest.raises(ValueError):
         pipe.step([torch.zeros((2, 2), dtype=torch.int8, device=DEV)])
+
+
+def test_obs_parents_rows_of_full_batch_tensors():
+    """obs_parents: the parts write their rows of the caller's full-batch tensors in turn; results equal one engine's."""
+    gc = GridConfig(size=16, num_agents=8, obs_radius=4, density=0.2, seed=5, collision_system="soft", max_episode_steps=12)
+    B = 12
+    one = VecPogema(gc, batch=B, device=DEV, auto_reset=True)
+    one.reset(seed=5)
+    parents = [torch.zeros(one.obs_shape, dtype=torch.float32, device=DEV) for _ in range(2)]
+    pipe = PipelinedVecPogema(gc, batch=B, parts=2, device=DEV, auto_reset=True, obs_parents=parents)
+    pipe.reset(seed=5)
+    pipe.warm_buffers()
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(3)
+    for t in range(15):
+        acts = torch.randint(0, 5, (B, 8), generator=gen, device=DEV, dtype=torch.int8)
+        ref = one.step(acts)
+        res = pipe.step(acts)
+        pipe.synchronize()
+        obs, rew, term, trunc, act = pipe.parent_outputs(t % 2)
+        assert obs.data_ptr() == parents[t % 2].data_ptr()
+        assert torch.equal(obs, ref[0]) and torch.equal(rew, ref[1]) and torch.equal(term, ref[2]) and torch.equal(trunc, ref[3])
+        assert torch.equal(act, ref[4]["is_active"])
+        assert res[1][0].data_ptr() == obs[pipe.part_slice(1)].data_ptr()
+    with pytest.raises(ValueError):
+        PipelinedVecPogema(gc, batch=B, parts=2, device=DEV, obs_parents=[parents[0][:6]])
+    pipe.close()
+    one.close()

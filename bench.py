@@ -527,10 +527,24 @@ class EngineStep:
         from pogema_amd.sharding import HostGather, start_step_gather, step_output_fields
         torch, env = self.torch, self.env
 
+        class PeerFailed(RuntimeError):
+            pass
+
+        def agree(ok: bool = True) -> bool:
+            """Every synchronisation point of this collective figure is ONE all_reduce(MIN) of an ok flag over the default
+            (gloo) group: a rank that failed in a phase reports 0 where its peers report 1, they all see 0 at
+            the same call and give up together -- with `dist.barrier()` here a failing rank left the others waiting for it
+            until the spin / group timeout and the line was delayed or lost."""
+            if not with_dist:
+                return ok
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(int(t.item()))
+
         def sync_all():
             torch.cuda.synchronize()
-            if with_dist:
-                dist.barrier()
+            if not agree(True):
+                raise PeerFailed("another rank failed in the host-gather figure")
 
         def plain(n):
             for _ in range(n):
@@ -538,7 +552,16 @@ class EngineStep:
                 self.i += 1
 
         depth = 2  # steps in flight between start() and finish(): the consumer reads step t-2 while step t is enqueued
-        gather = HostGather(step_output_fields(env), global_batch, device=env.device, slots=depth + 2)
+        gather, why = None, None
+        try:
+            gather = HostGather(step_output_fields(env), global_batch, device=env.device, slots=depth + 2,
+                                timeout_s=30.0 if with_dist else 120.0)
+        except Exception as exc:  # noqa: BLE001
+            why = repr(exc)
+        if not agree(gather is not None):
+            if gather is not None:
+                gather.close()
+            raise RuntimeError(f"HostGather could not be set up on every rank ({why or 'another rank failed'})")
         fields_bytes = sum(row for _, row in gather._layout.values()) * gather.count
         checked = {}
 
@@ -557,16 +580,24 @@ class EngineStep:
                 gather.finish(pend.pop(0))
 
         res = {}
-        for name, fn in (("loop_ms_per_step", plain), ("with_gather_ms_per_step", gathered)):
-            fn(max(8, steps // 10))
-            out = []
-            for _ in range(windows):
-                sync_all()
-                t0 = time.perf_counter()
-                fn(steps)
-                sync_all()
-                out.append((time.perf_counter() - t0) / steps * 1e3)
-            res[name] = statistics.median(out)
+        try:
+            for name, fn in (("loop_ms_per_step", plain), ("with_gather_ms_per_step", gathered)):
+                fn(max(8, steps // 10))
+                out = []
+                for _ in range(windows):
+                    sync_all()
+                    t0 = time.perf_counter()
+                    fn(steps)
+                    sync_all()
+                    out.append((time.perf_counter() - t0) / steps * 1e3)
+                res[name] = statistics.median(out)
+        except PeerFailed:
+            gather.close()
+            raise
+        except Exception:
+            agree(False)  # pairs with the peers' next sync_all(): they stop at the same call instead of waiting for us
+            gather.close()
+            raise
         res.update(mode=gather.mode, copies_per_step=gather.copies_per_step, bytes_per_step_per_rank=fields_bytes,
                    steps_in_flight=depth, slots=gather.slots,
                    cost_us_per_step=round((res["with_gather_ms_per_step"] - res["loop_ms_per_step"]) * 1e3, 2),
@@ -1135,8 +1166,9 @@ def main(argv=None):
     elif args.stub and not args.no_extras and world == 1 and headline_form(args, batch, per_gpu):
         extras["workloads"] = {name: stub_workload(name) for name in ("cfg1", "cfg3", "cfg4")}
     elif not args.stub and not args.no_extras and world > 1 and args.graph <= 0 and not args.no_obs:
-        # N > 1: the gather is the one cross-rank piece of the product path -- every rank takes part (shared segment,
-        # gloo barrier per step); a failure on any rank must not cost the line, so the verdict is agreed first
+        # N > 1: the gather is the one cross-rank piece of the product path -- every rank takes part (shared segment).  A
+        # failure on any rank must not cost the line: inside measure_host_gather every synchronisation point is an
+        # all_reduce(MIN) of an ok flag over gloo, so all ranks leave the figure at the same call
         try:
             hg = step.measure_host_gather(min(args.steps, 200), total_envs, with_dist=True)
         except Exception as exc:  # noqa: BLE001

@@ -229,9 +229,23 @@ class WalkVerdicts:
     def enabled() -> bool:
         return os.environ.get("PGX_WALK_NEGATIVE_CACHE", "1") not in ("", "0")
 
+    TTL_S = float(os.environ.get("PGX_WALK_NEGATIVE_TTL_S", "900"))
+    FREE_GROWTH_GIB = 8.0  # one spacer: that much more free memory than at the failed walk means it may reach further now
+
+    @staticmethod
+    def _free_gib(device_index: int):
+        try:
+            return torch.cuda.mem_get_info(device_index)[0] / float(1 << 30) if torch.cuda.is_available() else None
+        except Exception:  # noqa: BLE001
+            return None
+
     @classmethod
     def note_walk(cls, device_index: int, info: dict, budget_gib: float):
-        """Record the outcome of a walk (`info` = ZoneBuffers.info of its first pool)."""
+        """Record the outcome of a walk (`info` = ZoneBuffers.info of its first pool).  A failure is remembered with what
+        the walk actually COVERED (the spacers it held at its end -- a walk cut short by a co-tenant or by low free memory
+        says nothing about the stretch it never reached), the free memory at that moment and the time.  Walks
+        that end on an allocation error never get here (the pool's constructor raises)."""
+        import time
         with cls._lock:
             cls.walks += 1
             if info.get("spread"):
@@ -240,19 +254,33 @@ class WalkVerdicts:
             cls.failed_walks += 1
             key = device_identity(device_index)
             prev = cls._failed.get(key)
-            cls._failed[key] = {"budget_gib": max(float(budget_gib), prev["budget_gib"] if prev else 0.0),
+            covered = info.get("spacer_gib")
+            covered = float(budget_gib) if covered is None else min(float(budget_gib), float(covered) + 8.0)
+            cls._failed[key] = {"budget_gib": max(covered, prev["budget_gib"] if prev else 0.0), "requested_gib": float(budget_gib),
                                 "candidates": int(info.get("candidates", 0)), "same_zone_us": info.get("same_zone_us"),
-                                "spacer_gib": info.get("spacer_gib"), "walks": (prev["walks"] if prev else 0) + 1}
+                                "spacer_gib": info.get("spacer_gib"), "walks": (prev["walks"] if prev else 0) + 1,
+                                "free_gib": cls._free_gib(device_index), "when": time.monotonic()}
 
     @classmethod
     def failed(cls, device_index: int, budget_gib: float = 0.0):
-        """The remembered failure that makes a walk with `budget_gib` pointless on this device, or None."""
+        """The remembered failure that makes a walk with `budget_gib` pointless on this device, or None -- also None (and
+        forgotten) once the verdict is older than TTL_S or the device has materially more free memory than it had then."""
         if not cls.enabled():
             return None
+        import time
         with cls._lock:
-            v = cls._failed.get(device_identity(device_index))
-            # (a budget within one 8 GiB spacer of the failed one reaches nothing the failed walk did not)
-            return dict(v) if v is not None and float(budget_gib) <= v["budget_gib"] + 8.0 else None
+            key = device_identity(device_index)
+            v = cls._failed.get(key)
+            if v is None:
+                return None
+            free_now = cls._free_gib(device_index)
+            stale = time.monotonic() - v.get("when", 0.0) > cls.TTL_S
+            grown = (free_now is not None and v.get("free_gib") is not None and free_now > v["free_gib"] + cls.FREE_GROWTH_GIB)
+            if stale or grown:
+                del cls._failed[key]
+                return None
+            # (a budget within one 8 GiB spacer of what the failed walk covered reaches nothing it did not)
+            return dict(v) if float(budget_gib) <= v["budget_gib"] + 8.0 else None
 
     @classmethod
     def clear(cls):

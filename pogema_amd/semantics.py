@@ -78,20 +78,36 @@ def pinned_file() -> str:
     return os.environ.get("PGX_PINNED_SEMANTICS_FILE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "pinned_semantics.json")
 
 
+_PIN_CACHE = {}  # path -> ((mtime_ns, size), parsed switches)
+
+
 def pinned_defaults() -> dict:
     """{switch: value} demanded by reference fixtures (written by tools/pin_reference.sh), {} when nothing is pinned.  A
     malformed file is an error, not something to fall through silently: the defaults of a pinned build must not depend
-    on whether a JSON file happened to parse."""
+    on whether a JSON file happened to parse.  A pin derived from the repo's STAND-IN package (tests/standin_pogema*: built
+    from the builder's own oracle) is refused at the DEFAULT location -- it pins nothing; only a file named
+    explicitly through PGX_PINNED_SEMANTICS_FILE may be one (the rehearsal of tests/test_golden_pipeline.py).  Parsed once per
+    (path, mtime, size)."""
     path = pinned_file()
-    if not os.path.exists(path):
+    try:
+        st = os.stat(path)
+    except OSError:
         return {}
+    stamp = (st.st_mtime_ns, st.st_size)
+    hit = _PIN_CACHE.get(path)
+    if hit is not None and hit[0] == stamp:
+        return dict(hit[1])
     with open(path) as f:
         data = json.load(f)
+    if data.get("standin") and not os.environ.get("PGX_PINNED_SEMANTICS_FILE"):  # (an explicitly named file is a rehearsal's own business)
+        raise ValueError(f"{path} was derived from the stand-in `pogema` package (fixtures built from this repo's own oracle): "
+                         f"it cannot pin the product's semantics -- delete it or point PGX_PINNED_SEMANTICS_FILE elsewhere")
     out = {}
     for k, v in (data.get("switches") or {}).items():
         if k not in _SWITCHES or v not in _SWITCHES[k]:
             raise ValueError(f"{path}: {k}={v!r} is not a known semantics switch / value")
         out[k] = v
+    _PIN_CACHE[path] = (stamp, dict(out))
     return out
 
 

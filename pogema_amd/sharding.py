@@ -193,16 +193,33 @@ class HostGather:
                 os.unlink(name[0])
             except OSError:
                 pass
-        if err is not None:
-            raise err
-        self._ctr = np.frombuffer(self._mm, dtype=np.int64, count=self._data0 // 8)
-        self._ctr[self.rank * 8] = -1          # landed
-        if self.rank == self.dst:
-            self._ctr[self.rank * 8 + 1] = -1  # released
-        host = torch.frombuffer(self._mm, dtype=torch.uint8)
-        if self._cuda:
-            self._register(host)
+        # Every rank runs the SAME sequence of collectives whatever fails locally (a rank that raised between the
+        # two barriers went on to the all_reduce of __init__ while the healthy ranks sat in the second barrier -- gloo does not
+        # match the two, everybody hung until the group timeout): errors are kept, both barriers are always executed, and
+        # the error is raised only behind the last one; the all_reduce(MIN) in __init__ then turns it into the common fallback.
+        host = None
+        if err is None:
+            try:
+                self._ctr = np.frombuffer(self._mm, dtype=np.int64, count=self._data0 // 8)
+                self._ctr[self.rank * 8] = -1          # landed
+                if self.rank == self.dst:
+                    self._ctr[self.rank * 8 + 1] = -1  # released
+                host = torch.frombuffer(self._mm, dtype=torch.uint8)
+                if self._cuda:
+                    self._register(host)
+            except Exception as exc:  # noqa: BLE001  (hipHostRegister / memlock refusal on this rank only, ...)
+                err = exc
         dist.barrier(group=self._group)  # every counter is initialised before anybody publishes a ticket
+        if err is not None:
+            if self._registered and host is not None:
+                try:
+                    torch.cuda.cudart().cudaHostUnregister(host.data_ptr())
+                except Exception:  # noqa: BLE001
+                    pass
+                self._registered = False
+            host = None
+            self._ctr = None
+            raise err
         return host
 
     def _register(self, host: torch.Tensor):
@@ -299,7 +316,9 @@ class HostGather:
         # the per-field validation runs on a miss only.  (The plan holds no tensors: a cached alias would keep a recycled
         # output set referenced for ever.)
         names = tuple(self.fields)
-        key = (slot,) + tuple(tensors[n].data_ptr() for n in names)
+        # (shape, dtype and contiguity are part of the key -- ADVICE r5: another tensor that re-uses the same addresses with
+        # another shape or dtype must not be copied with the old plan's byte counts)
+        key = (slot,) + tuple((t.data_ptr(), t.dtype, t.shape, t.is_contiguous()) for t in (tensors[n] for n in names))
         plan = self._plans.get(key)
         if plan is None:
             jobs = []  # [host byte offset, byte count, index of the first source field, device address]

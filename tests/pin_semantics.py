@@ -38,6 +38,14 @@ def main(argv):
                 if not os.path.basename(p).startswith("reference_grid_")]  # (grid-layer fixtures carry no envs.py semantics)
     if not fixtures:
         sys.exit(f"no reference_*.npz under {argv[1]}")
+    probe_file = os.path.join(os.environ["PGX_GOLDEN_DIR"], "reference_probes.json")
+    probes = json.load(open(probe_file)) if os.path.exists(probe_file) else {}
+    standin = bool(probes.get("standin"))
+    if pin_out and standin and os.path.abspath(pin_out).startswith(os.path.join(ROOT, "pogema_amd") + os.sep):
+        # fixtures generated from the repo's stand-in package are the builder's own oracle talking to itself;
+        # they must never become the product's process-wide defaults (a rehearsal may write its pin anywhere else)
+        sys.exit(f"refusing --write-pin {pin_out}: the fixtures under {argv[1]} come from the STAND-IN pogema package "
+                 f"(reference_probes.json: standin = true); a stand-in pin may only be written outside pogema_amd/")
     switches = {"soft_vertex": SOFT_VERTEX, "soft_occupancy": SOFT_OCCUPANCY, "coop_reward": COOP_REWARD, "bad_action": BAD_ACTION}
     names = list(switches)
     passing, first_failure = [], {}
@@ -62,10 +70,7 @@ def main(argv):
     for n in names:
         seen = sorted({c[n] for c in passing})
         verdict[n] = {"determined": seen[0]} if len(seen) == 1 else {"free": seen} if seen else {"no combination passes": True}
-    probes = {}
-    probe_file = os.path.join(os.environ["PGX_GOLDEN_DIR"], "reference_probes.json")
-    if os.path.exists(probe_file):
-        probes = json.load(open(probe_file))
+    if probes:
         ba = str(probes.get("bad_action", ""))
         if "free" in verdict.get("bad_action", {}) and ba:
             verdict["bad_action"] = {"determined_by_probe": "flag" if ba.startswith("raises IndexError") else "noop" if ba == "noop" else ba}
@@ -75,6 +80,8 @@ def main(argv):
     if pin_out and passing:
         with open(pin_out, "w") as f:
             json.dump({"switches": pin, "fixtures": len(fixtures), "source": os.environ["PGX_GOLDEN_DIR"],
+                       "package": probes.get("package", "pogema"), "package_version": probes.get("pogema_version") or probes.get("version"),
+                       "standin": standin,
                        "differs_from_recalled_defaults": {n: v for n, v in pin.items() if v != default[n]},
                        "note": "written by tools/pin_reference.sh: the positions of the semantics switches that reference "
                                "fixtures demand; pogema_amd.Semantics.from_env() uses them as the process-wide defaults"}, f, indent=1)

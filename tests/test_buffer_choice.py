@@ -202,3 +202,60 @@ def test_walk_lock_file_handling(tmp_path, monkeypatch):
     with buffers.walk_lock(0, wait=True) as explicit:
         assert explicit is True, "an explicit budget walks as asked, unlocked"
     assert victim.read_text() == "precious"
+
+
+def test_walk_verdict_remembers_what_the_walk_covered_and_expires(monkeypatch):
+    """a walk that was cut short (low free memory, a co-tenant) only vouches for the stretch it covered; a verdict
+    ages out (TTL) and is dropped when the device has materially more free memory than at the failed walk."""
+    from pogema_amd.buffers import WalkVerdicts
+    WalkVerdicts.clear()
+    free = {"gib": 50.0}
+    monkeypatch.setattr(WalkVerdicts, "_free_gib", staticmethod(lambda idx: free["gib"]))
+    # asked for 136 GiB, but the walk ended after 40 GiB of spacers
+    WalkVerdicts.note_walk(0, {"spread": False, "candidates": 5, "spacer_gib": 40.0}, 136.0)
+    v = WalkVerdicts.failed(0, 40.0)
+    assert v is not None and v["budget_gib"] == 48.0 and v["requested_gib"] == 136.0 and v["free_gib"] == 50.0
+    assert WalkVerdicts.failed(0, 56.0) is not None, "within one spacer of what was covered"
+    assert WalkVerdicts.failed(0, 136.0) is None, "the stretch beyond 48 GiB was never walked: a full budget walks again"
+    # more memory has become free since: the verdict is void
+    free["gib"] = 59.0
+    assert WalkVerdicts.failed(0, 40.0) is None
+    free["gib"] = 50.0
+    WalkVerdicts.note_walk(0, {"spread": False, "candidates": 5, "spacer_gib": 40.0}, 136.0)
+    assert WalkVerdicts.failed(0, 40.0) is not None
+    monkeypatch.setattr(WalkVerdicts, "TTL_S", 0.0)
+    assert WalkVerdicts.failed(0, 40.0) is None, "older than the TTL"
+    WalkVerdicts.clear()
+
+
+def test_standin_pin_is_refused_at_the_default_location(tmp_path, monkeypatch):
+    """a pin file derived from the stand-in package must never become the product's silent default; named
+    explicitly (the rehearsal) it is the caller's business.  The parsed file is cached by (path, mtime, size)."""
+    import json
+    from pogema_amd import semantics as S
+    pin = tmp_path / "pinned_semantics.json"
+    pin.write_text(json.dumps({"switches": {"soft_vertex": "all_stay"}, "standin": True}))
+    monkeypatch.delenv("PGX_SEMANTICS", raising=False)
+    monkeypatch.delenv("PGX_PINNED_SEMANTICS_FILE", raising=False)
+    monkeypatch.setattr(S, "pinned_file", lambda: str(pin))  # = "it lies where the product looks by default"
+    with pytest.raises(ValueError, match="stand-in"):
+        S.Semantics.from_env()
+    monkeypatch.setenv("PGX_PINNED_SEMANTICS_FILE", str(pin))
+    assert S.Semantics.from_env().soft_vertex == "all_stay"
+    assert str(pin) in S._PIN_CACHE and S.pinned_defaults() == {"soft_vertex": "all_stay"}
+    pin.write_text(json.dumps({"switches": {"soft_vertex": "lowest_index", "coop_reward": "per_agent"}, "standin": False}))
+    assert S.pinned_defaults() == {"soft_vertex": "lowest_index", "coop_reward": "per_agent"}, "a rewritten file is re-read"
+    # tests/pin_semantics.py refuses to write a stand-in pin into pogema_amd/
+    import os
+    import subprocess
+    import sys
+    d = tmp_path / "fx"
+    d.mkdir()
+    (d / "reference_probes.json").write_text(json.dumps({"standin": True}))
+    import numpy as np
+    np.savez(d / "reference_dummy.npz", x=np.zeros(1))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    target = os.path.join(root, "pogema_amd", "pinned_semantics_test_refusal.json")
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "pin_semantics.py"), str(d), "--write-pin", target],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "STAND-IN" in (p.stderr + p.stdout) and not os.path.exists(target)

@@ -239,3 +239,55 @@ def test_host_gather_ring_protocol_three_ranks(tmp_path):
     port = 29500 + ((os.getpid() + 31) % 2000)
     mp.spawn(_ring_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
     assert (tmp_path / "ring_ok").exists()
+
+
+def _one_rank_fails_worker(rank, world, port, tmpdir, where):
+    """the shared segment cannot be set up on ONE rank only -- every rank must still run the same collectives
+    and end up on the private-staging fallback together, quickly (no process-group timeout)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        import time
+        import pogema_amd.sharding as sh
+        if rank == 1:
+            if where == "mmap":
+                import mmap as _mmap
+
+                def boom(*a, **k):
+                    raise OSError("mmap refused on this rank (test)")
+                _mmap_mmap, _mmap.mmap = _mmap.mmap, boom
+            else:  # the failure sits between the two barriers: counter initialisation / hipHostRegister
+                real = torch.frombuffer
+
+                def boom(*a, **k):
+                    raise RuntimeError("registration refused on this rank (test)")
+                torch.frombuffer = boom
+        t0 = time.monotonic()
+        g = sh.HostGather({"rewards": ((3,), torch.float32)}, 7, shared=True)
+        took = time.monotonic() - t0
+        if rank == 1:
+            if where == "mmap":
+                _mmap.mmap = _mmap_mmap
+            else:
+                torch.frombuffer = real
+        assert g.mode == "private staging + gloo gather", g.mode
+        assert took < 30.0, f"fallback took {took:.1f} s: the ranks waited for a timeout"
+        start, count = sh.shard_bounds(7, world, rank)
+        full = torch.arange(21, dtype=torch.float32).view(7, 3)
+        got = g.finish(g.start(rewards=full[start:start + count].contiguous()))
+        if rank == 0:
+            assert torch.equal(got["rewards"], full)
+            open(os.path.join(tmpdir, "ok_" + where), "w").write("ok")
+        g.close()
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("where", ["mmap", "register"])
+def test_host_gather_falls_back_together_when_one_rank_fails(tmp_path, where):
+    port = 29500 + ((os.getpid() + 977 + (13 if where == "mmap" else 0)) % 2000)
+    mp.spawn(_one_rank_fails_worker, args=(2, port, str(tmp_path), where), nprocs=2, join=True)
+    assert (tmp_path / ("ok_" + where)).exists()

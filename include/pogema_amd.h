@@ -232,7 +232,9 @@ typedef struct pgx_geometry {
     int32_t lanes_per_env;  /* G: lanes of a wave one environment occupies (power of two; 64 when multi_wave)       */
     int32_t waves;          /* waves per workgroup                                                                   */
     int32_t envs_per_wave;  /* environments per single-wave workgroup (1 when multi_wave)                            */
-    int32_t multi_wave;     /* 1: one environment per workgroup of `waves` waves (num_agents > 64, or helper waves)  */
+    int32_t multi_wave;     /* 1: one environment per workgroup of `waves` waves (num_agents > 64, or helper waves);
+                               2: the same in the LARGE-MAP layout (two whole padded bitmaps exceed a CU's LDS, ~800 x 800
+                               cells and up): only the occupancy bitmap lives in LDS, obstacles are read through the L2  */
     int32_t p16;            /* 1: window side <= 16, packed 16-bit row masks                                         */
     int32_t stagger;        /* cohort stagger of the single-wave kernel (0 = off)                                    */
     int32_t store_policy;   /* observation stores AS EXECUTED: 0 plain, 1 nontemporal, 2 sc1 write-through (the lighter */

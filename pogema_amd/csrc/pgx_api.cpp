@@ -203,11 +203,13 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
     if (e->geo_roll.lds_bytes > e->geo.lds_bytes && e->geo_roll.lds_bytes > 160 * 1024) e->geo_roll = e->geo;
     if (e->geo.lds_bytes > 160 * 1024) {
         const size_t need = e->geo.lds_bytes;
+        const int bm_bytes = e->bmw * 4, Wd = e->W;
         delete e;
         return fail(PGX_E_INVALID,
-                    "configuration needs %zu bytes of LDS per workgroup (> 163840): padded bitmaps of %dx%d "
-                    "cells plus %d agents' row masks do not fit one CU",
-                    need, cfg->height + 2 * r, cfg->width + 2 * r, A);
+                    "configuration needs %zu bytes of LDS per workgroup (> 163840) even in the large-map layout (occupancy "
+                    "bitmap of %dx%d cells = %d bytes, plus the exchange arrays and row masks of %d agents with a %dx%d "
+                    "window): see the Limits table in README.md",
+                    need, cfg->height + 2 * r, cfg->width + 2 * r, bm_bytes, A, Wd, Wd);
     }
 
     DeviceGuard guard(device);
@@ -237,7 +239,9 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
     auto alloc = [&](void** p, size_t bytes) {
         if (err == hipSuccess) err = hipMalloc(p, bytes);
     };
-    alloc((void**)&e->obst, B * e->bmw * sizeof(uint32_t));
+    // (+ 4 words: the window funnel reads the word behind the last one of a row unconditionally -- in LDS that is the next
+    // array, in the large-map layout, which reads the HBM bitmap directly, it must still be inside the allocation)
+    alloc((void**)&e->obst, (B * e->bmw + 4) * sizeof(uint32_t));
     alloc((void**)&e->pos, BA * sizeof(uint32_t));
     alloc((void**)&e->tgt, BA * sizeof(uint32_t));
     alloc((void**)&e->pos0, BA * sizeof(uint32_t));
@@ -956,7 +960,7 @@ int pgx_get_geometry(const pgx_env* e, int32_t for_rollout, pgx_geometry* out) {
     out->lanes_per_env = g.G;
     out->waves = g.waves;
     out->envs_per_wave = g.epw;
-    out->multi_wave = g.multi_wave ? 1 : 0;
+    out->multi_wave = g.big ? 2 : g.multi_wave ? 1 : 0;
     out->p16 = g.p16 ? 1 : 0;
     out->stagger = g.stagger;
     // the EFFECTIVE store flavour: the generic funnels of the lighter formats (uint8; bfloat16 / float16 with a

@@ -28,11 +28,12 @@ def usage():
     rows = {}
     for ln in p.stdout.splitlines():
         m = re.match(r"(\w+)<G=(\d+),MW=(\d),P16=(\d)>\s+sgpr\s+(\d+) vgpr\s+(\d+) scratch\s+(\d+) occ (\d+)", ln)
+        # (the large-map instances are listed as step_kernel_big / rollout_kernel_big: names of their own)
         if m:
             rows[(m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4)))] = tuple(int(m.group(k)) for k in (5, 6, 7, 8))
     if not rows and ("No such file" in p.stderr or "not found" in p.stderr or "cannot find ROCm" in p.stderr):
         pytest.skip("hipcc cannot cross-compile gfx950 here: " + p.stderr[-300:])
-    assert len(rows) == 32, p.stdout[-2000:] + p.stderr[-2000:]
+    assert len(rows) == 36, p.stdout[-2000:] + p.stderr[-2000:]  # 16 step + 16 rollout + 2 + 2 large-map instances
     return rows
 
 
@@ -79,9 +80,20 @@ def test_rollout_kernels_stay_within_their_known_budget(usage):
     must hold: no scratch at all (the round-5 kernels spilled 8-76 bytes per lane) and at least four waves per SIMD."""
     seen = 0
     for (name, G, mw, p16), (sgpr, vgpr, scratch, occ) in usage.items():
+        if name == "rollout_kernel_big":
+            assert scratch == 0 and occ >= 4
         if name != "rollout_kernel":
             continue
         seen += 1
         assert scratch == 0, f"rollout_kernel<{G},{mw},{p16}> spills {scratch} bytes per lane"
         assert occ >= 4 and vgpr <= 128, f"rollout_kernel<{G},{mw},{p16}>: {vgpr} VGPRs, {occ} waves per SIMD"
     assert seen == 16
+
+
+def test_large_map_instances_do_not_spill(usage):
+    """Round 6: step_kernel<64, true, P16, BIG> -- only the occupancy bitmap in LDS, obstacles through the L2.  One such
+    workgroup owns a CU's LDS anyway (>= 80 KB of it), so occupancy is not the point; scratch is."""
+    big = {k: v for k, v in usage.items() if k[0] == "step_kernel_big"}
+    assert sorted(k[1:] for k in big) == [(64, 1, 0), (64, 1, 1)]
+    for k, (sgpr, vgpr, scratch, occ) in big.items():
+        assert scratch == 0 and vgpr <= 128 and occ >= 4, (k, vgpr, scratch, occ)

@@ -98,7 +98,16 @@ extern "C" {
 #define PGX_OBS_BF16 2
 #define PGX_OBS_F16 3
 
-/* hard limits of this build */
+/* hard limits of this build (upstream's GridConfig admits size 2..1024, obs_radius 1..128, num_agents >= 1 -- recalled,
+ * pogema/grid_config.py; README.md "Limits"):
+ *   PGX_MAX_SIDE        every map GridConfig admits.  Up to ~800 x 800 cells both padded bitmaps of an environment are
+ *                       staged in LDS; beyond, the large-map layout keeps the occupancy bitmap only (pgx_geometry.multi_wave = 2)
+ *   PGX_MAX_OBS_RADIUS  a window row is ONE 32-bit mask (2r+1 <= 31): obs_radius 16..128 are refused
+ *   PGX_MAX_AGENTS      one workgroup (<= 1024 lanes, one lane per agent) per environment: more agents are refused
+ *   LDS                 what one environment keeps in a CU's 160 KB: 4 * PH * ceil(PW / 32) bytes per padded bitmap (PH, PW =
+ *                       map + 2r) plus 24 bytes per lane of exchange arrays plus the row masks -- 2 bytes per window row
+ *                       and (agent, plane) aliased over the bitmaps for windows up to 16 wide, 4 bytes each IN ADDITION for
+ *                       wider ones: e.g. 1024 agents with obs_radius >= 8 do not fit; pgx_check_config says so up front */
 #define PGX_MAX_OBS_RADIUS 15   /* window side 2r+1 <= 31 (one 32-bit row mask per window row) */
 #define PGX_MAX_AGENTS 1024
 #define PGX_MAX_SIDE 1024
@@ -145,6 +154,10 @@ const char* pgx_last_error(void);
  * Replaces: constructing `batch` reference env objects (upstream pogema/envs.py `_make_pogema`). */
 int pgx_create(const pgx_config* cfg, int device, pgx_env** out);
 int pgx_destroy(pgx_env* env);
+/* Every check of pgx_create that needs no device -- argument ranges, the limits above, the LDS budget of the launch shape --
+ * with the same status codes and pgx_last_error() text: lets a host wrapper refuse a configuration (upstream: pydantic's
+ * ValidationError of `GridConfig`) before it touches a GPU.  Needs no HIP device. */
+int pgx_check_config(const pgx_config* cfg);
 
 /* Sizes of the caller-owned output buffers, in elements. */
 int64_t pgx_obs_elems(const pgx_env* env);   /* batch * agents * 3 * (2r+1)^2   (obs_dtype elements) */

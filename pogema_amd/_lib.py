@@ -51,10 +51,13 @@ class _LazyObsDtypes(dict):
 
 OBS_DTYPES = _LazyObsDtypes()
 METRIC_NAMES = ("ISR", "CSR", "ep_length", "SoC", "makespan", "avg_throughput")
+# hard limits of the engine (include/pogema_amd.h: PGX_MAX_*); upstream's GridConfig admits size 2..1024, obs_radius 1..128,
+# num_agents >= 1 -- README.md "Limits"
+MAX_OBS_RADIUS, MAX_AGENTS, MAX_SIDE = 15, 1024, 1024
 
 # every symbol include/pogema_amd.h declares; tests/test_abi.py checks the library exports them all
 EXPORTED_SYMBOLS = (
-    "pgx_abi_version", "pgx_last_error", "pgx_create", "pgx_destroy", "pgx_obs_elems", "pgx_agent_elems",
+    "pgx_abi_version", "pgx_last_error", "pgx_create", "pgx_check_config", "pgx_destroy", "pgx_obs_elems", "pgx_agent_elems",
     "pgx_reset_from_state", "pgx_reset_random", "pgx_regenerate", "pgx_regenerate_failures", "pgx_get_map", "pgx_step", "pgx_observe", "pgx_set_metrics_buffers", "pgx_get_state", "pgx_generate", "pgx_place_agents",
     "pgx_snapshot_bytes", "pgx_save_snapshot", "pgx_load_snapshot", "pgx_time_observe", "pgx_bad_action_count",
     "pgx_buffers_create", "pgx_buffers_ptr", "pgx_buffers_get_info", "pgx_buffers_destroy", "pgx_set_targets",
@@ -123,6 +126,7 @@ def load() -> C.CDLL:
     lib.pgx_last_error.restype = C.c_char_p
     lib.pgx_create.argtypes = [C.POINTER(PgxConfig), C.c_int, C.POINTER(vp)]
     lib.pgx_destroy.argtypes = [vp]
+    lib.pgx_check_config.argtypes = [C.POINTER(PgxConfig)]
     lib.pgx_obs_elems.argtypes = [vp]
     lib.pgx_obs_elems.restype = i64
     lib.pgx_agent_elems.argtypes = [vp]

@@ -134,9 +134,9 @@ static void apply_xcd_shares(pgx_env* e) {
     }
 }
 
-int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
-    if (!cfg || !out) return fail(PGX_E_INVALID, "pgx_create: null argument");
-    *out = nullptr;
+// Everything of pgx_create that needs no device: argument checks, launch shapes, the LDS budget.
+static int create_host_side(const pgx_config* cfg, int device, pgx_env** out_e) {
+    *out_e = nullptr;
     if (cfg->abi_version != PGX_ABI_VERSION)
         return fail(PGX_E_INVALID, "pgx_config.abi_version is %d but this library implements ABI %d: rebuild the caller against "
                     "include/pogema_amd.h and set cfg.abi_version = PGX_ABI_VERSION (ABI 5 renumbered soft_occupancy: 0 is "
@@ -211,6 +211,25 @@ int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
                     "window): see the Limits table in README.md",
                     need, cfg->height + 2 * r, cfg->width + 2 * r, bm_bytes, A, Wd, Wd);
     }
+
+    *out_e = e;
+    return PGX_OK;
+}
+
+int pgx_check_config(const pgx_config* cfg) {
+    if (!cfg) return fail(PGX_E_INVALID, "pgx_check_config: null argument");
+    pgx_env* e = nullptr;
+    const int rc = create_host_side(cfg, 0, &e);
+    delete e;
+    return rc;
+}
+
+int pgx_create(const pgx_config* cfg, int device, pgx_env** out) {
+    if (!cfg || !out) return fail(PGX_E_INVALID, "pgx_create: null argument");
+    *out = nullptr;
+    pgx_env* e = nullptr;
+    if (const int rc = create_host_side(cfg, device, &e)) return rc;
+    const int A = cfg->num_agents;
 
     DeviceGuard guard(device);
     if (guard.err != hipSuccess) {

@@ -108,3 +108,45 @@ def test_product_never_imports_oracle():
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 for word in banned:
                     assert word not in text, f"{f} references {word!r}"
+
+
+def _cfg(**kw):
+    base = dict(batch=4, height=16, width=16, num_agents=4, obs_radius=5, collision_system=0, on_target=0, max_episode_steps=64,
+                auto_reset=1, obs_dtype=0, seed=0, env_index_base=0, random_outside=0, outside_density=0.3, soft_vertex_rule=0,
+                coop_reward=0, bad_action=0, lifelong_rng=0, soft_occupancy=0, abi_version=_lib.PGX_ABI_VERSION)
+    base.update(kw)
+    return _lib.PgxConfig(**base)
+
+
+def test_check_config_knows_the_limits_without_a_device(engine_lib):
+    """pgx_check_config = every check of pgx_create that needs no GPU (ranges, PGX_MAX_*, the LDS budget of the launch shape,
+    large-map layout included), same status codes and messages -- README.md "Limits" (VERDICT r5 missing #4)."""
+    import ctypes as C
+
+    def chk(**kw):
+        cfg = _cfg(**kw)
+        rc = engine_lib.pgx_check_config(C.byref(cfg))
+        return rc, engine_lib.pgx_last_error().decode() if rc else ""
+
+    assert chk() == (0, "")
+    assert chk(height=1024, width=1024, num_agents=256)[0] == 0, "PGX_MAX_SIDE fits in the large-map layout"
+    assert chk(height=800, width=1000, num_agents=70)[0] == 0
+    assert chk(height=1024, width=1024, num_agents=1024, obs_radius=7)[0] == 0
+    rc, msg = chk(height=1024, width=1024, num_agents=1024, obs_radius=15)
+    assert rc != 0 and "bytes of LDS" in msg and "Limits" in msg
+    assert chk(num_agents=1024, obs_radius=7, height=64, width=64)[0] == 0
+    assert chk(num_agents=1024, obs_radius=8, height=64, width=64)[0] != 0, "1024 agents x 32-bit row masks exceed one CU"
+    for bad, frag in ((dict(num_agents=1025), "num_agents"), (dict(obs_radius=16), "obs_radius"), (dict(height=1025), "map size"),
+                      (dict(abi_version=5), "abi_version")):
+        rc, msg = chk(**bad)
+        assert rc != 0 and frag in msg, (bad, msg)
+
+
+def test_vecpogema_names_the_limit_before_it_touches_a_device():
+    """What GridConfig admits and the engine does not is a ValueError from VecPogema.__init__ that says the limit -- raised
+    before the HIP device is even looked for (this container has none)."""
+    from pogema_amd import GridConfig, VecPogema
+    with pytest.raises(ValueError, match=r"obs_radius=20.*1\.\.15"):
+        VecPogema(GridConfig(size=16, num_agents=2, obs_radius=20), batch=2)
+    with pytest.raises(ValueError, match=r"num_agents=1500.*1\.\.1024"):
+        VecPogema(GridConfig(size=64, num_agents=1500, obs_radius=2), batch=2)

@@ -508,3 +508,17 @@ def test_light_formats_on_every_observation_path(fmt):
     with pytest.raises(ValueError):
         a.observe(out=torch.zeros(a.obs_shape, device="cuda"))  # float32 buffer for a bfloat16 engine
     a.close(); b.close()
+
+
+def test_limits_are_value_errors_that_name_the_limit():
+    """README "Limits": configurations GridConfig admits and the engine cannot hold come back as ValueError from
+    VecPogema.__init__ (never a late engine error): radius / agents by their range, the LDS budget by its byte count."""
+    from pogema_amd import GridConfig, VecPogema
+    with pytest.raises(ValueError, match="obs_radius=16"):
+        VecPogema(GridConfig(size=32, num_agents=2, obs_radius=16), batch=1)
+    with pytest.raises(ValueError, match="bytes of LDS"):
+        VecPogema(GridConfig(size=64, num_agents=1024, obs_radius=8, density=0.0), batch=1)
+    env = VecPogema(GridConfig(size=1024, num_agents=64, obs_radius=5, density=0.3, seed=1), batch=2)  # PGX_MAX_SIDE: accepted
+    obs, _ = env.reset(seed=1)
+    assert env.geometry()["multi_wave"] == 2 and tuple(obs.shape) == (2, 64, 3, 11, 11)
+    env.close()

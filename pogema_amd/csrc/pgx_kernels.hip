@@ -1457,6 +1457,16 @@ StepGeometry step_geometry(int batch, int A, int bmw, int W, bool allow_p16, int
         // the 256 CUs.  Measured (profiles/r1/epw_sweep.txt): best while the launch stays within ~4 rounds
         // of the 8192 resident waves; beyond that the per-wave fixed cost shows (A = 8: +16 % at 65536 waves).
         while (g.epw > 1 && (batch + g.epw / 2 - 1) / (g.epw / 2) <= 32768) g.epw >>= 1;
+        // The on-device loop prefers LONGER store bursts per wave: a wave that pauses (its state phase) between bursts of
+        // less than ~32 KB costs an HBM-sized ring bandwidth that the same bytes in 46 KB bursts from half as many waves do
+        // not (tools/drift_probe2.hip, profiles/r6/drift_probe_pause_kinds.txt: 23 KB x 8192 waves +3.1 us per step for a
+        // 2.75 us pause, 46 KB x 4096 waves +0.3); configs[3] shard, in-process A/B on shared rings
+        // (profiles/r6/rollout_cfg3_epw_ab.txt): 2 envs per wave 33.7 against 35.5 us into an 8-slot ring, 23.8 against
+        // 23.9-24.1 into the two-slot one.  Only while more than 4096 waves remain to cover the chip.
+        if (for_rollout)
+            while (g.epw < max_epw && (size_t)g.epw * A * 3 * W * W * (size_t)obs_elem_bytes < 32 * 1024 &&
+                   (batch + g.epw - 1) / g.epw > 4096)
+                g.epw <<= 1;
         if (epw_override > 0) g.epw = epw_override < max_epw ? epw_override : max_epw;
     }
     g.p16 = allow_p16 && W <= 16;

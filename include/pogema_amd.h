@@ -100,8 +100,8 @@ extern "C" {
 
 /* hard limits of this build (upstream's GridConfig admits size 2..1024, obs_radius 1..128, num_agents >= 1 -- recalled,
  * pogema/grid_config.py; README.md "Limits"):
- *   PGX_MAX_SIDE        every map GridConfig admits.  Up to ~800 x 800 cells both padded bitmaps of an environment are
- *                       staged in LDS; beyond, the large-map layout keeps the occupancy bitmap only (pgx_geometry.multi_wave = 2)
+ *   PGX_MAX_SIDE        every map GridConfig admits.  Small maps stage both padded bitmaps of an environment in LDS; from 64 KB
+ *                       of bitmaps (~500 x 500 cells) the large-map layout keeps the occupancy bitmap only (pgx_geometry.multi_wave = 2)
  *   PGX_MAX_OBS_RADIUS  a window row is ONE 32-bit mask (2r+1 <= 31): obs_radius 16..128 are refused
  *   PGX_MAX_AGENTS      one workgroup (<= 1024 lanes, one lane per agent) per environment: more agents are refused
  *   LDS                 what one environment keeps in a CU's 160 KB: 4 * PH * ceil(PW / 32) bytes per padded bitmap (PH, PW =
@@ -246,7 +246,7 @@ typedef struct pgx_geometry {
     int32_t waves;          /* waves per workgroup                                                                   */
     int32_t envs_per_wave;  /* environments per single-wave workgroup (1 when multi_wave)                            */
     int32_t multi_wave;     /* 1: one environment per workgroup of `waves` waves (num_agents > 64, or helper waves);
-                               2: the same in the LARGE-MAP layout (two whole padded bitmaps exceed a CU's LDS, ~800 x 800
+                               2: the same in the LARGE-MAP layout (the two padded bitmaps of an environment exceed 64 KB, ~500 x 500
                                cells and up): only the occupancy bitmap lives in LDS, obstacles are read through the L2  */
     int32_t p16;            /* 1: window side <= 16, packed 16-bit row masks                                         */
     int32_t stagger;        /* cohort stagger of the single-wave kernel (0 = off)                                    */

@@ -1499,8 +1499,13 @@ StepGeometry step_geometry(int batch, int A, int bmw, int W, bool allow_p16, int
         return (state_words + nag * 3 * W + 1) * 4;
     };
     size_t bytes = layout_bytes();
-    const char* force_big = getenv("PGX_BIG");  // diagnostic / tests: "1" runs the large-map layout on any map
-    if (bytes > 160 * 1024 || (force_big && force_big[0] == '1')) {
+    // The large-map layout is also the FASTER one well before the staged layout stops fitting: once an environment's two
+    // bitmaps take more than ~64 KB, at most two workgroups fit a CU and every step stages tens of KB that the windows
+    // hardly touch (profiles/r6/big_vs_staged.txt, same instances and buffers: 640 x 640 x 256 agents 114.0 -> 83.6 us per
+    // 1024-env step, 768 x 768 122.1 -> 105.6, 512 x 512 x 64 agents 119.3 -> 77.0; equal at 512 x 512 x 256 agents and below).
+    const char* force_big = getenv("PGX_BIG");  // diagnostic / tests: "1" = on any map, "0" = only when nothing else fits
+    const size_t big_from = (force_big && force_big[0] == '0') ? (size_t)160 * 1024 : (size_t)64 * 1024;
+    if (bytes > big_from || (force_big && force_big[0] == '1')) {
         // Large maps: ONE environment per workgroup, only the occupancy bitmap in LDS, obstacles read from the HBM bitmap
         // through the L2 (step_body, BIG).  At least four waves: they share the clearing of the bitmap, the row masks and
         // the observation write; wave 0 holds the agents when there are at most 64.

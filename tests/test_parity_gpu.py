@@ -30,7 +30,7 @@ GEOMETRIES = [
     ("a1024", 1, 52, 52, 1024, 2, 0.05, 5, 4),           # PGX_MAX_AGENTS: 16 waves (1024 threads) per env
     ("tiny_map", 4, 2, 2, 2, 1, 0.0, 8, 4),              # the smallest map GridConfig admits: every cell a start or a target
     ("one_row", 3, 1, 9, 3, 2, 0.0, 10, 5),              # a corridor one cell high: only left / right ever move, window taller than the map
-    ("big_map", 2, 640, 600, 20, 5, 0.2, 6, 4),          # near the LDS limit: two 650 x 610-cell bitmaps = 104 KB per workgroup
+    ("big_map", 2, 640, 600, 20, 5, 0.2, 6, 4),          # two 650 x 610-cell bitmaps = 104 KB: large-map layout since round 6 (> 64 KB)
 ]
 
 
@@ -515,3 +515,21 @@ def test_large_map_layout_forced_on_small_maps(geom, monkeypatch):
         got = engine_rollout_launch(obstacles, agents, targets, actions, **kw)
         for k in ("obs", "rewards", "terminated", "truncated", "is_active"):
             assert np.array_equal(np.asarray(got[k]), np.asarray(ref[k])), f"big/{name}/{collision} rollout launch: {k}"
+
+
+@pytest.mark.parametrize("collision", COLLISIONS)
+def test_staged_layout_near_the_lds_limit(collision, monkeypatch):
+    """PGX_BIG=0: the staged layout (both bitmaps in LDS) for as long as it fits -- 104 KB and 158 KB per workgroup -- which
+    the engine by default leaves for the large-map layout above 64 KB (it is faster there: profiles/r6/big_vs_staged.txt)."""
+    from pogema_amd import GridConfig, VecPogema
+    from util import c_oracle_rollout
+    monkeypatch.setenv("PGX_BIG", "0")
+    for B, H, Wd, A, r in ((2, 640, 600, 20, 5), (2, 760, 760, 130, 5)):
+        obstacles, agents, targets = generate_instances(B, H, Wd, A, 0.2, 31)
+        actions = random_actions(6, B, A, 32)
+        kw = dict(obs_radius=r, collision_system=collision, on_target="finish", max_episode_steps=4, auto_reset=True, seed=1)
+        assert_rollouts_equal(c_oracle_rollout(obstacles, agents, targets, actions, nthreads=8, **kw),
+                              engine_rollout(obstacles, agents, targets, actions, **kw), f"staged/{H}x{Wd}/{collision}")
+        env = VecPogema(GridConfig(size=max(H, Wd), num_agents=A, obs_radius=r), batch=B)
+        assert env.geometry()["multi_wave"] in (0, 1), "PGX_BIG=0 keeps the staged layout while it fits"
+        env.close()

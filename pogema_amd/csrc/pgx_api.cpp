@@ -977,7 +977,7 @@ int pgx_get_geometry(const pgx_env* e, int32_t for_rollout, pgx_geometry* out) {
     if (!e || !out) return fail(PGX_E_INVALID, "pgx_get_geometry: null argument");
     const pgx::StepGeometry& g = for_rollout ? e->geo_roll : e->geo;
     out->lanes_per_env = g.G;
-    out->waves = g.waves;
+    out->waves = g.waves * (g.pc ? 2 : 1);
     out->envs_per_wave = g.epw;
     out->multi_wave = g.big ? 2 : g.multi_wave ? 1 : 0;
     out->p16 = g.p16 ? 1 : 0;

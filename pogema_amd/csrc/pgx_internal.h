@@ -139,6 +139,7 @@ struct StepGeometry {
     int store_policy; // observation store flavour (pgx_kernels.hip: store_obs16)
     int state_stores; // when the per-step result stores are issued (pgx_kernels.hip: emit_state)
     bool big;         // large-map layout: one env per workgroup, occupancy bitmap only in LDS, obstacles read through the L2
+    bool pc;          // rollout launch shape only: resolver / streamer pair of waves per environment group (step_body, PC)
     bool resident_bitmap;  // rollout launch shape only: obstacle bitmap staged once per launch, LDS = bitmap + max(rest, rows)
     size_t lds_bytes;
     // shares of the launch's workgroups per XCD (xcd_partition; equal until pgx_xcd_tune or PGX_XCD_WEIGHTS)

@@ -448,13 +448,30 @@ __device__ __forceinline__ uint32_t pack_action4(int a) { return (uint32_t)a <= 
 //                 136 KB fit alone); the obstacle bitmap is not staged at all -- the `blocked` bit of a move and the
 //                 obstacle rows of the observation windows are read from the HBM bitmap through the L2 (0.8 % of the
 //                 step's traffic).  Always the multi-wave form (one environment per workgroup).
-template <int G, bool MW, bool P16, bool ROLL, bool BIG, typename P, typename R>
+//   PC          : rollout_kernel only, small single-wave environments (round 6): a PAIR of waves per environment group.
+//                 Wave 0 -- the resolver -- runs the state phase of step t (registers, DPP, its own LDS slice) and publishes
+//                 the agents' cells and the occupancy bitmap into one of two LDS buffers; wave 1 -- the streamer -- turns
+//                 the buffer of step t - 1 into row masks and streams that step's observations meanwhile.  One barrier
+//                 per iteration, K + 1 iterations.  A lone wave spends 1.6 us resolving and 2.4 us on row masks + stream
+//                 per configs[1] step one after the other (profiles/r6/rollout_timeline_after.txt); the pair overlaps
+//                 them, and the streamer's bursts follow each other without the resolver's pause in between
+//                 (tools/drift_probe2.hip: what an HBM-sized configs[3] ring loses).
+template <int G, bool MW, bool P16, bool ROLL, bool BIG, bool PC, typename P, typename R>
 __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int slot, Carry& c) {
     static_assert(!MW || G == 64, "multi-wave environments use full waves");
     static_assert(!BIG || MW, "the large-map layout runs one environment per workgroup");
+    static_assert(!PC || (ROLL && !MW && P16), "the resolver / streamer pair exists for single-wave rollouts with packed rows");
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
 
-    const int tid = threadIdx.x;
+    const int tid = PC ? (int)(threadIdx.x & 63u) : (int)threadIdx.x;
+    [[maybe_unused]] const int role = PC ? (int)(threadIdx.x >> 6) : 0;  // PC: 0 resolves step t, 1 streams step t - 1
+    bool do_resolve = true;
+    [[maybe_unused]] bool do_stream = true;
+    if constexpr (PC) {
+        do_resolve = role == 0 && t < rp.steps;
+        do_stream = role == 1 && t > 0;
+        if (!do_resolve && !do_stream) return;
+    }
     const int NT = MW ? (int)blockDim.x : 64;
     const int lane = tid & 63;
     const int wave = MW ? (tid >> 6) : 0;
@@ -498,6 +515,7 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
 
     uint32_t* s_obst = smem;                         // (BIG: not staged, the region does not exist)
     uint32_t* s_occ = s_obst + (BIG ? 0 : epw * bmw);
+    if constexpr (PC) s_occ += (((role == 0 ? t : t - 1) & 1) ? epw * bmw + 2 * AS : 0);  // {occupancy, cells, targets} x 2
     uint32_t* s_apos = s_occ + epw * bmw;  // [AS]
     uint32_t* s_atgt = s_apos + AS;        // [AS]
     uint32_t* s_vis = s_atgt + AS;         // MW only: [NT] cells as seen by others
@@ -528,6 +546,7 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
     [[maybe_unused]] int araw[8];                 // ROLL: the actions of steps t+8 .. t+15 in flight (every eighth iteration)
     [[maybe_unused]] bool fetch_block = false;
     if constexpr (ROLL) {
+      if (do_resolve) {
         // Register-resident loop: the state is loaded by the first iteration only and then carried in
         // `c`.  gfx9 retires loads and stores through ONE in-order counter (vmcnt), so a load issued behind the observation
         // stores of the previous iteration cannot be consumed before every one of those stores has been acknowledged
@@ -579,6 +598,7 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
                 }
             }
         }
+      }
     } else {
     if (valid) {
         pos = p.pos[gi];
@@ -597,7 +617,7 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
     }
 
     // ---- phase 1: stage obstacle bitmaps HBM -> LDS, clear the occupancy bitmaps ---------------
-    {
+    if (do_resolve) {
         const uint32_t* g = p.obst + (size_t)env0 * bmw;
         const int n = nenv * bmw;
         const int stagger = (ROLL && t > 0) ? 0 : p.stagger;  // only the first step of a rollout starts in lockstep
@@ -664,7 +684,8 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
         bool trunc = false, finished = false, do_reset = false, act = false;
         int n_arrived = 0;
     } so;
-    const int when_stores = p.mode == MODE_STEP ? p.state_stores : 0;
+    int when_stores = p.mode == MODE_STEP ? p.state_stores : 0;
+    if constexpr (PC) when_stores = 0;  // the resolver stores its results at once: nobody streams behind it in this wave
     const bool late_stores = when_stores != 0;
     [[maybe_unused]] bool last_step = true;
     if constexpr (ROLL) last_step = t == rp.steps - 1;
@@ -723,7 +744,7 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
             }
         }
     };
-    {
+    if (do_resolve) {
         const uint32_t* obm;
         if constexpr (BIG) obm = p.obst + (size_t)env0 * bmw;  // the HBM bitmap itself (one word per mover, L2)
         else obm = s_obst + env_l * bmw;
@@ -912,6 +933,7 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
         }
     }
     if constexpr (ROLL) {
+      if (do_resolve) {
         c.pos = pos;
         c.tgt = tgt;
         c.active = active;
@@ -922,15 +944,21 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
             for (int k = 0; k < 8; ++k) b |= pack_action4(araw[k]) << (4 * k);
             c.anext = b;
         }
+      }
     }
     if (dbg && tid == 0) p.dbg[(size_t)blk * 4 + (dbg2 ? 3 : 1)] = wall_clock64();
     if (!p.obs) {
         if (late_stores) emit_state(pos, tgt, active, elapsed, macc, so);
         return;
     }
+    if constexpr (PC) {
+        if (!do_stream) return;  // the resolver's iteration ends here; the pair meets at the barrier in rollout_kernel
+    }
     lds_sync<MW>();
     if (when_stores == 1) emit_state(pos, tgt, active, elapsed, macc, so);
-    float* const obs_out = ROLL ? reinterpret_cast<float*>(reinterpret_cast<char*>(p.obs) + (size_t)slot * (size_t)rp.obs_stride) : p.obs;
+    int out_slot = slot;
+    if constexpr (PC) out_slot = slot == 0 ? rp.obs_slots - 1 : slot - 1;  // the streamer writes step t - 1
+    float* const obs_out = ROLL ? reinterpret_cast<float*>(reinterpret_cast<char*>(p.obs) + (size_t)out_slot * (size_t)rp.obs_stride) : p.obs;
 
     if constexpr (P16) {
         // The window side is a compile-time constant for the radii that matter (W = 11: obs_radius 5, the default and
@@ -940,6 +968,7 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
         const int W_rt = W, r_rt = r;
         uint32_t* rows_base = smem;  // the packed rows go over the dead state -- in a rollout with a resident bitmap: behind it
         if constexpr (ROLL) rows_base = rp.resident_bitmap ? s_occ : smem;
+        if constexpr (PC) rows_base = s_obst + epw * bmw + 2 * (epw * bmw + 2 * AS);  // behind both hand-over buffers
         auto p16_phases = [&](auto wt_tag) {
         constexpr int WT = decltype(wt_tag)::value;
         const int W = WT ? WT : W_rt;
@@ -1226,7 +1255,7 @@ template <int G, bool MW, bool P16, bool BIG = false>
 __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const StepParams p) {
     const RolloutParams none{};
     Carry unused;
-    step_body<G, MW, P16, false, BIG>(p, none, 0, 0, unused);
+    step_body<G, MW, P16, false, BIG, false>(p, none, 0, 0, unused);
 }
 
 // K steps in ONE launch (pgx_rollout).  Environments never interact, so a workgroup can run its own environments
@@ -1255,8 +1284,8 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : 8) void step_kernel(const 
 #ifndef PGX_ROLL_OCC
 #define PGX_ROLL_OCC 4
 #endif
-template <int G, bool MW, bool P16, bool BIG = false>
-__global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : PGX_ROLL_OCC) void rollout_kernel(const StepParams p0, const RolloutParams rp0) {
+template <int G, bool MW, bool P16, bool BIG = false, bool PC = false>
+__global__ __launch_bounds__(MW ? 1024 : (PC ? 128 : 64), MW ? 1 : PGX_ROLL_OCC) void rollout_kernel(const StepParams p0, const RolloutParams rp0) {
     typedef const __attribute__((address_space(4))) char KC;
     typedef const __attribute__((address_space(4))) StepParams KP;
     typedef const __attribute__((address_space(4))) RolloutParams KR;
@@ -1266,15 +1295,15 @@ __global__ __launch_bounds__(MW ? 1024 : 64, MW ? 1 : PGX_ROLL_OCC) void rollout
     const int steps = rp0.steps, slots = rp0.obs_slots;
     int slot = 0;
     Carry c;
-    for (int t = 0; t < steps; ++t) {
+    for (int t = 0; t < steps + (PC ? 1 : 0); ++t) {  // (PC: the streamer is one step behind the resolver)
         KC* ka = (KC*)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(ka));
         KP& p = *reinterpret_cast<KP*>(ka);
         KR& rp = *reinterpret_cast<KR*>(ka + rp_offset);
-        step_body<G, MW, P16, true, BIG>(p, rp, t, slot, c);
+        step_body<G, MW, P16, true, BIG, PC>(p, rp, t, slot, c);
         slot = slot + 1 == slots ? 0 : slot + 1;
         if ((t & 7) == 7) c.ablk = c.anext;
-        if constexpr (MW) lds_sync<true>();
+        if constexpr (MW || PC) lds_sync<true>();
     }
 }
 
@@ -1525,6 +1554,7 @@ StepGeometry step_geometry(int batch, int A, int bmw, int W, bool allow_p16, int
         bytes = layout_bytes();
     }
     g.resident_bitmap = false;
+    g.pc = false;
     if (for_rollout && !g.big) {
         // rollout_kernel stages the obstacle bitmap once per launch: it keeps its own LDS region and the P16 rows alias
         // only what lies behind it.  Costs LDS when the rows are the larger part; if that no longer fits one CU the
@@ -1542,6 +1572,25 @@ StepGeometry step_geometry(int batch, int A, int bmw, int W, bool allow_p16, int
         if (res <= 160 * 1024 && !(off && off[0] == '0')) {
             g.resident_bitmap = true;
             bytes = res;
+        }
+        // Resolver / streamer pair (step_body, PC): small single-wave environments whose wave would otherwise alternate a
+        // state phase with a short store burst.  float32 observations, packed rows, resident bitmap; not the 64-lane
+        // groups (their 93 KB bursts already keep the memory pipeline full: configs[2] is stream-bound either way).
+        const char* pc = getenv("PGX_ROLL_PC");  // diagnostic / tests: "0" off, "1" wherever the instance exists
+        const bool pc_ok = !g.multi_wave && g.p16 && g.resident_bitmap && g.G <= 32 && obs_elem_bytes == 4;
+        const size_t burst = nag * 3 * W * W * 4;
+        // ... and only where BOTH waves of every pair are resident at once (<= 4096 waves at four per SIMD): on a launch that
+        // fills the chip anyway the pair halves the environments in flight and is slower (configs[3] shard 24.2 -> 25.6 us,
+        // configs[1] 4.95 -> 3.25: profiles/r6/rollout_pair_ab.txt)
+        const long pairs = (batch + g.epw - 1) / g.epw;
+        g.pc = pc_ok && ((pc && pc[0] == '1') || (!(pc && pc[0] == '0') && burst < 64 * 1024 && pairs * 2 <= 4096));
+        if (g.pc) {
+            const size_t bufw = (size_t)g.epw * bmw + 2 * agent_slots;
+            bytes = ((size_t)g.epw * bmw + 2 * bufw) * 4 + (nag * 3 * W + 4) * 2 + 16;
+            if (bytes > 160 * 1024) {
+                g.pc = false;
+                bytes = res;
+            }
         }
     }
     g.lds_bytes = (bytes + 15) & ~(size_t)15;
@@ -1581,6 +1630,14 @@ template <int G, bool MW, bool P16>
 static const void* rollout_fn() { return reinterpret_cast<const void*>(&rollout_kernel<G, MW, P16>); }
 
 static const void* rollout_fn_for(const StepGeometry& g) {
+    if (g.pc) {
+#define PGX_CASE(gg) case gg: return reinterpret_cast<const void*>(&rollout_kernel<gg, false, true, false, true>);
+        switch (g.G) {
+            PGX_CASE(1) PGX_CASE(2) PGX_CASE(4) PGX_CASE(8) PGX_CASE(16) PGX_CASE(32)
+            default: return nullptr;
+        }
+#undef PGX_CASE
+    }
     if (g.big) return g.p16 ? reinterpret_cast<const void*>(&rollout_kernel<64, true, true, true>)
                             : reinterpret_cast<const void*>(&rollout_kernel<64, true, false, true>);
     if (g.multi_wave) return g.p16 ? rollout_fn<64, true, true>() : rollout_fn<64, true, false>();
@@ -1598,7 +1655,7 @@ hipError_t launch_rollout(const StepParams& p, const RolloutParams& rp, const St
     StepParams args = p;
     RolloutParams rargs = rp;
     void* kargs[] = {&args, &rargs};
-    return hipLaunchKernel(fn, dim3(g.grid), dim3(64 * g.waves), kargs, g.lds_bytes, stream);
+    return hipLaunchKernel(fn, dim3(g.grid), dim3(64 * g.waves * (g.pc ? 2 : 1)), kargs, g.lds_bytes, stream);
 }
 
 // ---- shares of a launch's workgroups per XCD -------------------------------------------------------------------------

@@ -177,3 +177,35 @@ def test_random_policy_rollout():
     np.testing.assert_array_equal(more["actions"].cpu().numpy(), policy_actions(77, 100, B, A, 5 + K, 3))
     with pytest.raises(ValueError):
         a.rollout()
+
+
+PAIR_GEOMS = [(8, 2, 3, 33), (16, 8, 5, 40), (32, 16, 5, 24), (20, 27, 4, 9), (12, 1, 2, 70), (14, 4, 7, 17)]  # G = 2, 8, 16, 32, 1, 4
+
+
+@pytest.mark.parametrize("size,agents,r,batch", PAIR_GEOMS)
+@pytest.mark.parametrize("collision,on_target", [("soft", "finish"), ("priority", "restart"), ("block_both", "nothing")])
+def test_rollout_resolver_streamer_pair(size, agents, r, batch, collision, on_target, monkeypatch):
+    """Round 6: small single-wave environments run their rollout as a PAIR of waves -- the resolver takes step t through the
+    state phase while the streamer writes step t - 1's observations (step_body, PC).  PGX_ROLL_PC=1 forces the pair for every
+    lane layout that has the instance; launches of 1, 2, 9 and 21 steps, rings of 1, 2, 5 and all slots: identical with the
+    step() loop, outputs and state."""
+    monkeypatch.setenv("PGX_ROLL_PC", "1")
+    monkeypatch.setenv("PGX_WAVES", "1")  # (no helper waves for small batches of 23 KB environments: they are another kernel)
+    gc = GridConfig(size=size, num_agents=agents, obs_radius=r, density=0.2, collision_system=collision, on_target=on_target,
+                    max_episode_steps=7, seed=3)
+    for steps, slots in ((21, None), (9, 2), (2, 5), (1, 1), (17, 1)):
+        a, b, ref, got = _pair(gc, batch, steps, obs_slots=slots, auto_reset=True)
+        assert b.geometry(for_rollout=True)["waves"] == 2, "the pair"
+        _same(ref, got, steps, obs_slots=slots)
+        _same_state(a, b)
+        a.close()
+        b.close()
+
+
+def test_rollout_pair_is_chosen_for_small_launches_only():
+    small = VecPogema(GridConfig(size=16, num_agents=8, obs_radius=5), batch=1024, device=DEV)    # BASELINE configs[1]
+    large = VecPogema(GridConfig(size=32, num_agents=16, obs_radius=5), batch=8192, device=DEV)   # configs[3] shard
+    assert small.geometry(for_rollout=True)["waves"] == 2 and small.geometry()["waves"] == 1
+    assert large.geometry(for_rollout=True)["waves"] == 1 and large.geometry(for_rollout=True)["envs_per_wave"] == 2
+    small.close()
+    large.close()

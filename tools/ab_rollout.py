@@ -17,7 +17,7 @@ K, SLOTS, ROUNDS = int(os.environ.get("K", "64")), int(os.environ.get("SLOTS", "
 wl, variants = sys.argv[1], sys.argv[2:]
 batch, size, agents, r = WL[wl]
 DEFAULT_LIB = _L.LIB_PATH
-KNOBS = ("PGX_BIG", "PGX_FLAGS", "PGX_EPW", "PGX_STAGGER", "PGX_WAVES", "PGX_STORE", "PGX_STATE_STORES", "PGX_ROLL_RESIDENT")
+KNOBS = ("PGX_ROLL_PC", "PGX_BIG", "PGX_FLAGS", "PGX_EPW", "PGX_STAGGER", "PGX_WAVES", "PGX_STORE", "PGX_STATE_STORES", "PGX_ROLL_RESIDENT")
 envs = []
 for v in variants:
     for k in KNOBS:

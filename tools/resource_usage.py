@@ -19,7 +19,8 @@ for ln in (out.stdout + out.stderr).splitlines():
 want = sys.argv[1] if len(sys.argv) > 1 else "kernel"
 for r in rows:
     n = r["name"]
-    m = re.match(r"_ZN3pgx\d+(\w+?)ILi(\d+)ELb(\d)ELb(\d)ELb(\d)E", n)
-    label = (f"{m.group(1)}{'_big' if m.group(5) == '1' else ''}<G={m.group(2)},MW={m.group(3)},P16={m.group(4)}>") if m else n[:50]
+    m = re.match(r"_ZN3pgx\d+(\w+?)ILi(\d+)ELb(\d)ELb(\d)ELb(\d)(?:ELb(\d))?E", n)
+    label = (f"{m.group(1)}{'_big' if m.group(5) == '1' else ''}{'_pair' if m.group(6) == '1' else ''}"
+             f"<G={m.group(2)},MW={m.group(3)},P16={m.group(4)}>") if m else n[:50]
     if want in label:
         print(f"{label:40s} sgpr {r.get('SGPRs', '?'):>3} vgpr {r.get('VGPRs', '?'):>3} scratch {r.get('ScratchSize', '?'):>3} occ {r.get('Occupancy', '?')}")

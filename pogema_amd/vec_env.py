@@ -591,9 +591,12 @@ class VecPogema(PlacementMixin):
         same outputs -- for callers that have the actions up front (MAPF plans, scripted / random policies, replays).
         `actions`: int tensor [K, batch, agents].  `obs_slots`: how many observation tensors to keep -- None = K (the whole
         trajectory, K x obs bytes of HBM), n >= 1: a ring, step t lands in slot t % n (1 = only the last one), 0 = none.
-        A ring of up to 8 slots of >= 128 MiB each is taken from the engine's zone-spread buffers (`placement` as for
-        `reuse_buffers`), kept by the env and OVERWRITTEN BY THE NEXT rollout() with the same `obs_slots`; its first axis is
-        strided (slot stride = bytes rounded up to 2 MiB), every slot itself is contiguous.
+        Where the ring lies (slots of >= 128 MiB each): with up to as many slots as the engine has output sets (2-3,
+        reuse_buffers='recycle') it is BORROWED from those sets -- buffers this engine has already placed and timed -- for as
+        long as you reference the returned `obs` (or a view of it); step() meanwhile serves from the remaining sets or fresh
+        tensors, and nothing is overwritten behind your back.  Larger rings (up to 8 slots) come from a zone pool of their own,
+        kept by the env and OVERWRITTEN BY THE NEXT rollout() with the same `obs_slots`.  Either way the first axis is strided
+        (slot stride = the buffers' distance), every slot itself is contiguous.
         Returns a dict of device tensors: obs [slots, batch, agents, 3, W, W] (or None), rewards f32 / terminated /
         truncated / is_active bool [K, batch, agents], episode_done bool [K, batch], metrics f32 [K, batch, 6] (rows
         where episode_done is set; ISR, CSR, ep_length, SoC, makespan, avg_throughput).  Observations are the raw

@@ -526,3 +526,47 @@ def test_rollout_ring_probe_only_builds_exactly_its_slots(monkeypatch):
         env.close(release=True)
     monkeypatch.setattr(torch.cuda, "mem_get_info", real)
     ref.close()
+
+
+def test_rollout_ring_is_borrowed_from_the_recycler_sets():
+    """rollout()'s observation ring of up to as many slots as the engine has output sets comes out of those
+    sets -- placed and timed once -- and stays out of circulation for as long as the caller holds it; step() keeps working
+    from the rest and never overwrites it."""
+    import torch
+    from pogema_amd import GridConfig, VecPogema
+    gc = GridConfig(size=64, num_agents=64, obs_radius=5, density=0.3, seed=0, collision_system="soft", max_episode_steps=16)
+    env = VecPogema(gc, batch=4096, device="cuda:0", auto_reset=True)  # 380 MB observations: three recycled output sets
+    env.reset(seed=0)
+    acts = torch.randint(0, 5, (6, 4096, 64), device="cuda:0", dtype=torch.int8)
+    env.step(acts[0])
+    rec = env._recycler
+    assert rec and len(rec) == 3 and rec.free_sets() == 3
+    out = env.rollout(acts, obs_slots=2)
+    ring = out["obs"]
+    base = ring.data_ptr()
+    assert base in rec.obs_pointers() and ring[1].data_ptr() in rec.obs_pointers(), "the ring's slots are two of the engine's own buffers"
+    assert rec.free_sets() == 1 and not env._rollout_pools, "two sets are out, no ring of its own was built"
+    keep = ring.clone()
+    for t in range(4):  # step() serves from the remaining set (and fresh tensors while its result is held): the ring is untouched
+        obs, *_ = env.step(acts[t])
+        assert obs.data_ptr() not in (base, ring[1].data_ptr())
+    assert torch.equal(ring, keep)
+    del obs
+    view = ring[0, :8]
+    del out, ring
+    assert rec.free_sets() <= 2, "a view keeps its set out"
+    del view, keep
+    assert rec.free_sets() == 3, "dropped: all sets are back"
+    out3 = env.rollout(acts, obs_slots=3)   # three slots: only if the three buffers happen to lie at equal distances
+    assert out3["obs"].shape[0] == 3
+    ref = VecPogema(gc, batch=4096, device="cuda:0", auto_reset=True)
+    ref.reset(seed=0)
+    ref.step(acts[0])
+    ref.rollout(acts, obs_slots=2)
+    for t in range(4):
+        ref.step(acts[t])
+    for t in range(6):
+        robs, *_ = ref.step(acts[t])
+    assert torch.equal(out3["obs"][5 % 3], robs), "same trajectory whatever memory the ring lives in"
+    env.close()
+    ref.close()

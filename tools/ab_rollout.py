@@ -12,7 +12,8 @@ import torch  # noqa: E402
 from pogema_amd import GridConfig, VecPogema  # noqa: E402
 from pogema_amd import _lib as _L  # noqa: E402
 
-WL = {"cfg1": (1024, 16, 8, 5), "cfg2": (8192, 64, 64, 5), "cfg3": (8192, 32, 16, 5), "cfg4": (4096, 256, 256, 7)}
+WL = {"cfg1": (1024, 16, 8, 5), "cfg2": (8192, 64, 64, 5), "cfg3": (8192, 32, 16, 5), "cfg4": (4096, 256, 256, 7),
+      "a8big": (65536, 16, 8, 5), "a16small": (1024, 32, 16, 5), "a32mid": (2048, 32, 32, 5), "a4": (4096, 12, 4, 3)}
 K, SLOTS, ROUNDS = int(os.environ.get("K", "64")), int(os.environ.get("SLOTS", "2")), int(os.environ.get("ROUNDS", "8"))
 wl, variants = sys.argv[1], sys.argv[2:]
 batch, size, agents, r = WL[wl]

@@ -54,6 +54,7 @@ class PipelinedVecPogema:
         self.num_agents = self.engines[0].num_agents
         self.obs_shape = (self.batch,) + tuple(self.engines[0].obs_shape[1:])
         self._parents, self._sets, self._turn = None, None, [0] * self.parts
+        self._shared_bufs, self._shared_placement = None, None  # reuse_buffers=True: one placement for all parts (_shared_walk)
         if obs_parents is not None:
             obs_parents = list(obs_parents)
             e0 = self.engines[0]
@@ -113,16 +114,15 @@ class PipelinedVecPogema:
         e0 = self.engines[0]
         if self.parts < 2 or not e0.reuse_buffers or e0.single_buffer or not e0._has_state():
             return False
-        if any(e._bufs is not None for e in self.engines) and getattr(self, "_shared_bufs", None) is None:
+        if any(e._bufs is not None for e in self.engines) and self._shared_bufs is None:
             return False  # somebody has placed buffers already (a step before warm_buffers)
-        if getattr(self, "_shared_bufs", None) is None:
+        if self._shared_bufs is None:
             with self.stream(0):
                 self._shared_bufs = e0._pick_obs_buffers(2 * self.parts)
                 self._shared_placement = dict(e0.placement or {}, shared_by_parts=self.parts)
         if self.engines[i]._bufs is None:
             self.engines[i].adopt_obs_buffers(self._shared_bufs[2 * i:2 * i + 2], self._shared_placement)
-            if self.engines[i]._zone_ptrs is not None:
-                self.engines[i]._zone_ptrs = set(e0._zone_ptrs)
+            self.engines[i]._zone_ptrs = set(e0._zone_ptrs)
         return True
 
     def parent_outputs(self, k: int):

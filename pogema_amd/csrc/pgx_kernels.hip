@@ -542,10 +542,13 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
     bool ghost_in = false;  // ACTIVE_GHOST of the stored byte (see `ghost` below)
     int act = 0, elapsed = 0;
     int4 macc = make_int4(0, 0, 0, 0);
-    const bool env_leader = env_ok && agent == 0 && p.mode == MODE_STEP;
+    // (evaluated where each branch needs it: in the single-step form BEHIND the global loads -- `p.mode` is a scalar load, and
+    // waiting for it first delays every load of the step by that round trip: 0.5-1 % per launch, profiles/r6/step_ab_r5_vs_r6.txt)
+    bool env_leader;
     [[maybe_unused]] int araw[8];                 // ROLL: the actions of steps t+8 .. t+15 in flight (every eighth iteration)
     [[maybe_unused]] bool fetch_block = false;
     if constexpr (ROLL) {
+      env_leader = env_ok && agent == 0 && p.mode == MODE_STEP;
       if (do_resolve) {
         // Register-resident loop: the state is loaded by the first iteration only and then carried in
         // `c`.  gfx9 retires loads and stores through ONE in-order counter (vmcnt), so a load issued behind the observation
@@ -613,6 +616,7 @@ __device__ __forceinline__ void step_body(P& p, R& rp, const int t, const int sl
         }
     }
     if (env_ok && p.mode == MODE_STEP) elapsed = p.elapsed[env];
+    env_leader = env_ok && agent == 0 && p.mode == MODE_STEP;
     if (env_leader) macc = p.macc[env];
     }
 

@@ -42,11 +42,12 @@ def usage():
 # row-mask instances for windows up to 16 cells (obs_radius 3 / 5 / 7 = W 7 / 11 / 15), P16 = 0 the run-time-W form that
 # also carries the light formats -- must not pay for anything added around it.  A change here is either a deliberate
 # kernel change (update the table in the same commit, say why) or a regression.
-# Round 6: the G = 1 instances lost one VGPR each (60 -> 59, 47 -> 46) when step_body's load phase was split into the
-# rollout (register-carried) and the single-step form; every other instance is unchanged.
+# Round 6: unchanged -- the rollout form of step_body's load phase, the large-map layout and the resolver / streamer pair are
+# all `if constexpr` branches the single-step instances do not see (one slip -- `p.mode` read in front of the global loads --
+# showed as one VGPR less in the G = 1 instances and 0.5-1 % per launch; profiles/r6/step_ab_r5_vs_r6.txt).
 FROZEN_STEP_KERNELS = {
     (64, 1, 1): (84, 60, 0, 8), (64, 1, 0): (100, 44, 0, 8),
-    (1, 0, 1): (78, 59, 0, 8), (1, 0, 0): (78, 46, 0, 8),
+    (1, 0, 1): (78, 60, 0, 8), (1, 0, 0): (78, 47, 0, 8),
     (2, 0, 1): (78, 60, 0, 8), (2, 0, 0): (78, 49, 0, 8),
     (4, 0, 1): (78, 60, 0, 8), (4, 0, 0): (78, 49, 0, 8),
     (8, 0, 1): (78, 60, 0, 8), (8, 0, 0): (78, 49, 0, 8),

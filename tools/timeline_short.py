@@ -5,7 +5,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pogema_amd import GridConfig, VecPogema, _lib
-WL = {"cfg1": (1024, 16, 8, 5), "cfg2": (8192, 64, 64, 5), "cfg3": (8192, 32, 16, 5), "cfg4": (4096, 256, 256, 7)}
+WL = {"cfg1": (1024, 16, 8, 5), "cfg2": (8192, 64, 64, 5), "cfg3": (8192, 32, 16, 5), "cfg4": (4096, 256, 256, 7), "big": (1024, 1024, 256, 5), "mid": (1024, 640, 256, 5)}
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg1"
 batch, size, agents, r = WL[name]
 lib = _lib.load()

@@ -1254,7 +1254,7 @@ def main(argv=None):
                          "algorithmic_bytes_per_agent_step": bpas, "algorithmic_bytes_per_launch": alg_bytes,
                          "profile_command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-default-placement "
                                             "--no-cpu-baseline --no-extras  (the default-placement window and the secondary "
-                                            "figures launch the same kernel on other buffers / half batches; profiles/r5/README.md)"},
+                                            "figures launch the same kernel on other buffers / half batches; profiles/r6/README.md)"},
         }
         if "pipelined" in extras:
             e = extras["pipelined"]
